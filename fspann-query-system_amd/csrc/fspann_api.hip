@@ -1,0 +1,836 @@
+// fspann_api.hip — implementation of include/fspann.h for gfx950 (MI355X).
+// Product code.  No CPU fallback exists: every compute entry point launches a
+// HIP kernel or fails with FSPANN_E_DEVICE.  Nothing here references oracle/.
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <new>
+#include <numeric>
+
+#include "encode.hip.h"
+#include "refine.hip.h"
+#include "route.hip.h"
+
+using namespace fspann;
+
+namespace {
+
+int next_pow2(int64_t v) {
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return static_cast<int>(p);
+}
+
+int effective_probes(const fspann_ctx* c, int override_) {  // PIS:880-888
+    if (override_ > 0) return override_;
+    if (c->cfg.probe_override > 0) return c->cfg.probe_override;
+    return c->cfg.default_probes;
+}
+
+int java_final_cap_host(int cap0, int64_t n) {
+    int cap = cap0;
+    int64_t thr = static_cast<int64_t>(static_cast<float>(cap) * 0.75f);
+    while (n > thr && cap < (1 << 30)) {
+        const int oldCap = cap;
+        cap <<= 1;
+        thr = (oldCap >= 16) ? (thr << 1) : static_cast<int64_t>(static_cast<float>(cap) * 0.75f);
+    }
+    return cap;
+}
+
+void free_dev(void*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+template <typename T> void free_devt(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int upload_index(fspann_ctx* c) {
+    const int TD = c->TD, W = c->W;
+    for (int td = 0; td < TD; td++)
+        if (!c->h_table_set[td]) return fail(FSPANN_E_STATE, "table %d was never set (fspann_set_index)", td);
+    c->h_tables.assign(TD, RouteTable{});
+    int64_t parts = 0, offs = 0, ids = 0;
+    for (int td = 0; td < TD; td++) {
+        RouteTable& t = c->h_tables[td];
+        t.part_base = parts;
+        t.off_base = offs;
+        t.ids_base = ids;
+        t.nparts = static_cast<int32_t>(c->h_min[td].size());
+        parts += t.nparts;
+        offs += t.nparts + 1;
+        ids += static_cast<int64_t>(c->h_ids[td].size());
+    }
+    c->total_parts = parts;
+    c->total_ids = ids;
+    free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
+    std::vector<int64_t> keys2(static_cast<size_t>(std::max<int64_t>(parts, 1)) * 2);
+    std::vector<uint64_t> rep(static_cast<size_t>(std::max<int64_t>(parts, 1)) * W);
+    std::vector<int32_t> off(static_cast<size_t>(offs));
+    std::vector<int32_t> idv(static_cast<size_t>(std::max<int64_t>(ids, 1)));
+    for (int td = 0; td < TD; td++) {
+        const RouteTable& t = c->h_tables[td];
+        for (int p = 0; p < t.nparts; p++) {
+            keys2[(t.part_base + p) * 2 + 0] = c->h_min[td][p];
+            keys2[(t.part_base + p) * 2 + 1] = c->h_max[td][p];
+            for (int w = 0; w < W; w++) rep[(t.part_base + p) * W + w] = c->h_rep[td][static_cast<size_t>(p) * W + w];
+        }
+        for (int p = 0; p <= t.nparts; p++) off[t.off_base + p] = static_cast<int32_t>(c->h_off[td][p]);
+        std::copy(c->h_ids[td].begin(), c->h_ids[td].end(), idv.begin() + t.ids_base);
+    }
+    FSP_HIP(hipMalloc(&c->d_tables, sizeof(RouteTable) * TD));
+    FSP_HIP(hipMalloc(&c->d_keys2, keys2.size() * 8));
+    FSP_HIP(hipMalloc(&c->d_rep, rep.size() * 8));
+    FSP_HIP(hipMalloc(&c->d_off, std::max<size_t>(off.size(), 1) * 4));
+    FSP_HIP(hipMalloc(&c->d_ids, idv.size() * 4));
+    FSP_HIP(hipMemcpy(c->d_tables, c->h_tables.data(), sizeof(RouteTable) * TD, hipMemcpyHostToDevice));
+    FSP_HIP(hipMemcpy(c->d_keys2, keys2.data(), keys2.size() * 8, hipMemcpyHostToDevice));
+    FSP_HIP(hipMemcpy(c->d_rep, rep.data(), rep.size() * 8, hipMemcpyHostToDevice));
+    if (!off.empty()) FSP_HIP(hipMemcpy(c->d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    FSP_HIP(hipMemcpy(c->d_ids, idv.data(), idv.size() * 4, hipMemcpyHostToDevice));
+    c->dev_index_dirty = false;
+    return FSPANN_OK;
+}
+
+template <typename TIn>
+int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_dev, int32_t* hashes_dev,
+                  int32_t* bad_dev, double* proj_dev = nullptr) {
+    const int m = c->cfg.m;
+    const int tdPerBlock = std::max(1, kEncThreads / m);
+    const int gy = (c->TD + tdPerBlock - 1) / tdPerBlock;
+    // QB queries per block: 8 for bulk coding (index build), 4 for query batches so that
+    // a 1024-query batch still fills 256 CUs.
+    if (nq >= 8192) {
+        constexpr int QB = 8;
+        dim3 grid(static_cast<unsigned>((nq + QB - 1) / QB), gy);
+        hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), grid, dim3(kEncThreads), 0, c->stream, q_dev, nq,
+                           c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD,
+                           tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev);
+    } else {
+        constexpr int QB = 2;
+        dim3 grid(static_cast<unsigned>((nq + QB - 1) / QB), gy);
+        hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), grid, dim3(kEncThreads), 0, c->stream, q_dev, nq,
+                           c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD,
+                           tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev);
+    }
+    FSP_HIP(hipGetLastError());
+    return FSPANN_OK;
+}
+
+struct RoutePlan {
+    int P, S, max_tuples, maxcand, ht_size, ht_shift, sort_cap_lds, use_lds_ht, nbins;
+    size_t lds_bytes;
+    int grid;
+    int threads;
+    int64_t g_sort_stride;
+};
+
+int plan_route(fspann_ctx* c, int probe_override, int64_t nq, RoutePlan& pl) {
+    pl.P = effective_probes(c, probe_override);
+    pl.S = c->cfg.block_size;
+    const int64_t mt = static_cast<int64_t>(c->TD) * pl.P * pl.S;
+    if (mt > (1LL << kSeqBits)) return fail(FSPANN_E_RANGE, "T*D*probes*blockSize = %lld exceeds 2^%d tuple slots", (long long)mt, kSeqBits);
+    pl.max_tuples = static_cast<int>(mt);
+    pl.maxcand = static_cast<int>(std::min<int64_t>(mt, static_cast<int64_t>(c->hard_cap) - 1 + pl.S));
+    pl.ht_size = std::max(64, next_pow2(static_cast<int64_t>(pl.maxcand) + pl.maxcand / 3 + 1));
+    pl.ht_shift = 32 - __builtin_ctz(pl.ht_size);
+    pl.nbins = c->bits + 1;
+    const int full_sort = next_pow2(std::max(pl.maxcand, 1));
+    const size_t fixed = static_cast<size_t>(pl.max_tuples) * 4 + static_cast<size_t>(pl.nbins) * 4 +
+                         static_cast<size_t>(c->TD) * pl.P * 8 + static_cast<size_t>(c->TD) * 4 + 64;
+    const size_t budget = static_cast<size_t>(c->lds_limit) - 2048;  // static __shared__ + margin
+    if (fixed + 1024 * 8 > budget)
+        return fail(FSPANN_E_RANGE, "route: %d tuple slots per query do not fit in LDS (%zu B needed)", pl.max_tuples, fixed);
+    pl.use_lds_ht = 1;
+    pl.sort_cap_lds = full_sort;
+    const size_t ht_bytes = static_cast<size_t>(pl.ht_size) * 8;
+    while (pl.sort_cap_lds > 1024 && fixed + ht_bytes + static_cast<size_t>(pl.sort_cap_lds) * 8 > budget) pl.sort_cap_lds >>= 1;
+    if (fixed + ht_bytes + static_cast<size_t>(pl.sort_cap_lds) * 8 > budget) {
+        pl.use_lds_ht = 0;
+        pl.sort_cap_lds = full_sort;
+        while (pl.sort_cap_lds > 1024 && fixed + static_cast<size_t>(pl.sort_cap_lds) * 8 > budget) pl.sort_cap_lds >>= 1;
+    }
+    pl.lds_bytes = fixed + (pl.use_lds_ht ? ht_bytes : 0) + static_cast<size_t>(pl.sort_cap_lds) * 8;
+    pl.threads = 512;
+    pl.grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * 4));
+    pl.g_sort_stride = (pl.sort_cap_lds < full_sort) ? full_sort : 0;
+    return FSPANN_OK;
+}
+
+template <typename TC, typename TQ>
+int launch_refine_t(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int64_t B, const int32_t* cand_ids,
+                    const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
+                    int32_t* scored) {
+    constexpr int DC = (sizeof(TC) == 4) ? 32 : 16;
+    constexpr int VN = VecOf<TC>::N;
+    const int d = c->cfg.dim;
+    const int nchunks = static_cast<int>((B + kRefRows - 1) / kRefRows);
+    RefinePartial* partial = nullptr;
+    int32_t* pcnt = nullptr;
+    if (nchunks > 1) {
+        const size_t pb = static_cast<size_t>(nq) * nchunks * k * sizeof(RefinePartial);
+        const size_t cb = static_cast<size_t>(nq) * nchunks * 2 * 4;
+        int rc = ensure(c, c->ws_refine, pb + cb + 64);
+        if (rc) return rc;
+        partial = static_cast<RefinePartial*>(c->ws_refine.p);
+        pcnt = reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_refine.p) + ((pb + 15) & ~size_t(15)));
+    }
+    const bool vec = (d % VN == 0) && ((reinterpret_cast<uintptr_t>(cand) & 15) == 0);
+    const size_t lds = static_cast<size_t>((d + 1) & ~1) * 8 + static_cast<size_t>(DC) * (kRefRows + 1) * sizeof(TC);
+    const unsigned grid = static_cast<unsigned>(nq * nchunks);
+    if (vec) {
+        auto kern = refine_scan_kernel<TC, TQ, DC, true>;
+        if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, B, d, cand_ids, cand_count, k,
+                           nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
+    } else {
+        auto kern = refine_scan_kernel<TC, TQ, DC, false>;
+        if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, B, d, cand_ids, cand_count, k,
+                           nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
+    }
+    FSP_HIP(hipGetLastError());
+    if (nchunks > 1) {
+        hipLaunchKernelGGL(refine_merge_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), 0, c->stream, partial, pcnt,
+                           nchunks, k, out_ids, out_dist, out_count, scored);
+        FSP_HIP(hipGetLastError());
+    }
+    return FSPANN_OK;
+}
+
+#define CHECK_CTX(c)                                                      \
+    do {                                                                  \
+        if (!(c)) return fail(FSPANN_E_NULL, "ctx is null");              \
+        hipError_t _e = hipSetDevice((c)->device);                        \
+        if (_e != hipSuccess) return fail(FSPANN_E_DEVICE, "hipSetDevice(%d): %s", (c)->device, hipGetErrorString(_e)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* fspann_last_error(void) { return last_error_ref().c_str(); }
+const char* fspann_version(void) { return "fspann-hip 0.1 (gfx950)"; }
+
+int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
+    if (!cfg || !out) return fail(FSPANN_E_NULL, "cfg/out is null");
+    *out = nullptr;
+    fspann_cfg g = *cfg;
+    if (g.block_size <= 0) g.block_size = 64;
+    if (g.default_probes <= 0) g.default_probes = 5;
+    if (g.max_global_candidates <= 0) g.max_global_candidates = 20000;
+    if (g.refinement_limit <= 0) g.refinement_limit = 20000;
+    if (g.tables <= 0 || g.divisions <= 0 || g.m <= 0 || g.lambda <= 0 || g.dim <= 0)
+        return fail(FSPANN_E_ARG, "tables, divisions, m, lambda, dim must be > 0");
+    if (g.lambda > 32) return fail(FSPANN_E_ARG, "lambda > 32 is not supported (h_j is an int32)");
+    if (g.m > kEncThreads) return fail(FSPANN_E_ARG, "m > %d is not supported", kEncThreads);
+    if (g.block_size > 1024) return fail(FSPANN_E_ARG, "block_size > 1024 is not supported");
+    const int64_t bits = static_cast<int64_t>(g.m) * g.lambda;
+    if (bits >= (1 << kScoreBits)) return fail(FSPANN_E_ARG, "m*lambda = %lld exceeds %d code bits", (long long)bits, (1 << kScoreBits) - 1);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(FSPANN_E_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(FSPANN_E_ARG, "device %d out of range [0,%d)", device, ndev);
+    FSP_HIP(hipSetDevice(device));
+    fspann_ctx* c = new (std::nothrow) fspann_ctx();
+    if (!c) return fail(FSPANN_E_NOMEM, "out of host memory");
+    c->device = device;
+    c->cfg = g;
+    c->TD = g.tables * g.divisions;
+    c->bits = static_cast<int>(bits);
+    c->W = (c->bits + 63) / 64;
+    c->P_total = c->TD * g.m;
+    c->hard_cap = std::max(g.max_global_candidates, g.refinement_limit);  // PIS:612-615
+    c->cap0 = table_size_for(std::min(c->hard_cap, 1 << 16));             // PIS:619
+    if (c->cap0 < 64) {
+        delete c;
+        return fail(FSPANN_E_ARG, "max(maxGlobalCandidates, refinementLimit) < 33: HashMap order with a table shorter "
+                                  "than MIN_TREEIFY_CAPACITY is not modelled");
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (prop.sharedMemPerBlock > 0) c->lds_limit = static_cast<int>(std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024));
+        if (prop.maxSharedMemoryPerMultiProcessor > 0)
+            c->lds_limit = static_cast<int>(std::min<size_t>(std::max<size_t>(prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor), 160 * 1024));
+    }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(FSPANN_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->h_min.resize(c->TD); c->h_max.resize(c->TD); c->h_off.resize(c->TD); c->h_rep.resize(c->TD); c->h_ids.resize(c->TD);
+    c->h_table_set.assign(c->TD, 0);
+    *out = c;
+    return FSPANN_OK;
+}
+
+void fspann_ctx_destroy(fspann_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega);
+    free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
+    free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
+    free_dev(c->d_store);
+    free_dev(c->ws_route.p); free_dev(c->ws_refine.p);
+    for (auto& b : c->ws_io) free_dev(b.p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* fspann_ctx_stream(fspann_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+int fspann_sync(fspann_ctx* c) {
+    CHECK_CTX(c);
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    return FSPANN_OK;
+}
+
+int fspann_set_gfunctions(fspann_ctx* c, const double* alpha, const double* r, const double* omega) {
+    CHECK_CTX(c);
+    if (!alpha || !r || !omega) return fail(FSPANN_E_NULL, "alpha/r/omega is null");
+    const int P = c->P_total, d = c->cfg.dim;
+    for (int p = 0; p < P; p++)
+        if (!(omega[p] > 0.0)) return fail(FSPANN_E_ARG, "omega_j <= 0");  // Coding.java:84-86
+    std::vector<double> aT(static_cast<size_t>(d) * P);
+    for (int p = 0; p < P; p++)
+        for (int i = 0; i < d; i++) aT[static_cast<size_t>(i) * P + p] = alpha[static_cast<size_t>(p) * d + i];
+    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega);
+    FSP_HIP(hipMalloc(&c->d_alphaT, aT.size() * 8));
+    FSP_HIP(hipMalloc(&c->d_r, static_cast<size_t>(P) * 8));
+    FSP_HIP(hipMalloc(&c->d_omega, static_cast<size_t>(P) * 8));
+    FSP_HIP(hipMemcpy(c->d_alphaT, aT.data(), aT.size() * 8, hipMemcpyHostToDevice));
+    FSP_HIP(hipMemcpy(c->d_r, r, static_cast<size_t>(P) * 8, hipMemcpyHostToDevice));
+    FSP_HIP(hipMemcpy(c->d_omega, omega, static_cast<size_t>(P) * 8, hipMemcpyHostToDevice));
+    if (c->h_alpha.data() != alpha) { c->h_alpha.assign(alpha, alpha + static_cast<size_t>(P) * d); c->h_r.assign(r, r + P); c->h_omega.assign(omega, omega + P); }
+    c->have_g = true;
+    return FSPANN_OK;
+}
+
+// GFunctionRegistry.initialize (idx/GFunctionRegistry.java:63-147) = T*D x Coding.buildFromSample
+// (idx/Coding.java:184-241).  Host: SplittableRandom + Box-Muller rows (glibc log/cos — like any
+// non-JVM generator NOT bit-portable to HotSpot); device: the sample's projections
+// y = dot(v, alpha_j) with the exact fp64 kernel, from which omega_j = max(1e-6, max-min)/2.5.
+int fspann_registry_initialize(fspann_ctx* c, const double* sample, int64_t ns, int64_t base_seed) {
+    CHECK_CTX(c);
+    if (!sample) return fail(FSPANN_E_NULL, "sample");
+    if (ns <= 0) return fail(FSPANN_E_ARG, "Sample vectors cannot be empty");
+    const int TD = c->TD, m = c->cfg.m, d = c->cfg.dim, P = c->P_total, D = c->cfg.divisions;
+    struct Rng {
+        uint64_t s;
+        uint64_t nextLong() {
+            s += 0x9E3779B97F4A7C15ULL;
+            uint64_t z = s;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            return z ^ (z >> 31);
+        }
+        double nextDouble() { return static_cast<double>(nextLong() >> 11) * 0x1.0p-53; }
+    };
+    std::vector<double> alpha(static_cast<size_t>(P) * d), r(P, 0.0), w(P, 1.0);
+    std::vector<Rng> rngs(TD);
+    for (int td = 0; td < TD; td++) {
+        const int t = td / D, dv = td % D;
+        Rng& g = rngs[td];
+        g.s = static_cast<uint64_t>(base_seed + static_cast<int64_t>(t) * 1000003LL + dv);  // computeSeed :291-293
+        for (int j = 0; j < m; j++) {
+            double* row = alpha.data() + (static_cast<size_t>(td) * m + j) * d;
+            double norm = 0.0;
+            for (int i = 0; i < d; i++) {
+                const double u1 = std::max(4.9e-324, g.nextDouble());
+                const double u2 = g.nextDouble();
+                const double mag = std::sqrt(-2.0 * std::log(u1));
+                const double v = mag * std::cos(2.0 * M_PI * u2);
+                row[i] = v;
+                norm += v * v;
+            }
+            norm = std::sqrt(std::max(1e-12, norm));
+            for (int i = 0; i < d; i++) row[i] /= norm;
+        }
+    }
+    int rc = fspann_set_gfunctions(c, alpha.data(), r.data(), w.data());
+    if (rc) return rc;
+    // projections of the sample on the device (sequential fp64 == Coding.dot)
+    const size_t sb = static_cast<size_t>(ns) * d * 8, pb = static_cast<size_t>(ns) * P * 8;
+    if ((rc = ensure(c, c->ws_io[0], sb))) return rc;
+    if ((rc = ensure(c, c->ws_io[1], static_cast<size_t>(ns) * TD * c->W * 8))) return rc;
+    if ((rc = ensure(c, c->ws_io[2], static_cast<size_t>(ns) * 4))) return rc;
+    if ((rc = ensure(c, c->ws_io[3], pb))) return rc;
+    FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, sample, sb, hipMemcpyHostToDevice, c->stream));
+    rc = launch_encode<double>(c, ns, static_cast<const double*>(c->ws_io[0].p), static_cast<uint64_t*>(c->ws_io[1].p), nullptr,
+                               static_cast<int32_t*>(c->ws_io[2].p), static_cast<double*>(c->ws_io[3].p));
+    if (rc) return rc;
+    std::vector<double> proj(static_cast<size_t>(ns) * P);
+    std::vector<int32_t> bad(static_cast<size_t>(ns));
+    FSP_HIP(hipMemcpyAsync(proj.data(), c->ws_io[3].p, pb, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipMemcpyAsync(bad.data(), c->ws_io[2].p, static_cast<size_t>(ns) * 4, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < ns; i++)
+        if (bad[i]) { c->have_g = false; return fail(FSPANN_E_ARG, "Vector contains NaN/Inf (sample %lld)", (long long)i); }
+    for (int p = 0; p < P; p++) {
+        double mn = INFINITY, mx = -INFINITY;
+        for (int64_t s = 0; s < ns; s++) {
+            const double y = proj[static_cast<size_t>(s) * P + p];
+            if (y < mn) mn = y;
+            if (y > mx) mx = y;
+        }
+        const double range = std::max(1e-6, mx - mn);
+        double omega = range / 2.5;  // OMEGA_DIVISOR
+        if (!(omega > 0)) omega = 1e-3;
+        w[p] = omega;
+    }
+    for (int td = 0; td < TD; td++)
+        for (int j = 0; j < m; j++) r[td * m + j] = rngs[td].nextDouble() * w[td * m + j];  // one draw per j, after all alpha
+    c->h_alpha = alpha; c->h_r = r; c->h_omega = w;
+    rc = fspann_set_gfunctions(c, alpha.data(), r.data(), w.data());
+    return rc;
+}
+
+int fspann_get_gfunctions(fspann_ctx* c, double* alpha, double* r, double* omega) {
+    CHECK_CTX(c);
+    if (!c->have_g || c->h_alpha.empty()) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized");
+    if (alpha) std::copy(c->h_alpha.begin(), c->h_alpha.end(), alpha);
+    if (r) std::copy(c->h_r.begin(), c->h_r.end(), r);
+    if (omega) std::copy(c->h_omega.begin(), c->h_omega.end(), omega);
+    return FSPANN_OK;
+}
+
+int fspann_set_index(fspann_ctx* c, int td, int64_t n_parts, const int64_t* min_key, const int64_t* max_key,
+                     const uint64_t* rep, const int64_t* id_off, const int32_t* ids) {
+    CHECK_CTX(c);
+    if (td < 0 || td >= c->TD) return fail(FSPANN_E_ARG, "td %d out of range [0,%d)", td, c->TD);
+    if (n_parts < 0) return fail(FSPANN_E_ARG, "n_parts < 0");
+    if (n_parts > 0 && (!min_key || !max_key || !rep || !id_off || !ids)) return fail(FSPANN_E_NULL, "index array is null");
+    if (n_parts > 0 && id_off[0] != 0) return fail(FSPANN_E_ARG, "id_off[0] must be 0");
+    for (int64_t p = 0; p < n_parts; p++) {
+        const int64_t sz = id_off[p + 1] - id_off[p];
+        if (sz < 0 || sz > c->cfg.block_size)
+            return fail(FSPANN_E_ARG, "partition %lld of table %d has %lld ids (block_size %d)", (long long)p, td, (long long)sz, c->cfg.block_size);
+    }
+    const int64_t nid = n_parts > 0 ? id_off[n_parts] : 0;
+    if (nid >= (1LL << 31)) return fail(FSPANN_E_RANGE, "table has >= 2^31 ids");
+    if (c->n_ids > 0)
+        for (int64_t i = 0; i < nid; i++)
+            if (ids[i] < 0 || ids[i] >= c->n_ids) return fail(FSPANN_E_ARG, "id handle %d out of range [0,%lld)", ids[i], (long long)c->n_ids);
+    c->h_min[td].assign(min_key, min_key + n_parts);
+    c->h_max[td].assign(max_key, max_key + n_parts);
+    c->h_rep[td].assign(rep, rep + n_parts * c->W);
+    if (n_parts > 0) c->h_off[td].assign(id_off, id_off + n_parts + 1); else c->h_off[td].assign(1, 0);
+    c->h_ids[td].assign(ids, ids + nid);
+    c->h_table_set[td] = 1;
+    c->dev_index_dirty = true;
+    return FSPANN_OK;
+}
+
+int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, const uint8_t* deleted) {
+    CHECK_CTX(c);
+    if (n_ids <= 0 || n_ids >= (1LL << 31)) return fail(FSPANN_E_ARG, "n_ids out of range");
+    c->h_java_hash.resize(static_cast<size_t>(n_ids));
+    if (java_hash) std::copy(java_hash, java_hash + n_ids, c->h_java_hash.begin());
+    else for (int64_t i = 0; i < n_ids; i++) c->h_java_hash[i] = decimal_string_hash(i);
+    free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
+    FSP_HIP(hipMalloc(&c->d_java_hash, static_cast<size_t>(n_ids) * 4));
+    FSP_HIP(hipMemcpy(c->d_java_hash, c->h_java_hash.data(), static_cast<size_t>(n_ids) * 4, hipMemcpyHostToDevice));
+    if (deleted) {
+        bool any = false;
+        std::vector<uint32_t> bits(static_cast<size_t>((n_ids + 31) / 32), 0u);
+        for (int64_t i = 0; i < n_ids; i++)
+            if (deleted[i]) { bits[i >> 5] |= (1u << (i & 31)); any = true; }
+        if (any) {
+            FSP_HIP(hipMalloc(&c->d_deleted_bits, bits.size() * 4));
+            FSP_HIP(hipMemcpy(c->d_deleted_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    c->n_ids = n_ids;
+    return FSPANN_OK;
+}
+
+int fspann_finalize(fspann_ctx* c) {
+    CHECK_CTX(c);
+    if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized");
+    if (c->n_ids <= 0) return fail(FSPANN_E_STATE, "id metadata not set (fspann_set_id_meta)");
+    if (c->dev_index_dirty) {
+        int rc = upload_index(c);
+        if (rc) return rc;
+    }
+    c->frozen = true;
+    return FSPANN_OK;
+}
+
+int fspann_index_dims(fspann_ctx* c, int td, int64_t* n_parts, int64_t* n_ids) {
+    CHECK_CTX(c);
+    if (td < 0 || td >= c->TD) return fail(FSPANN_E_ARG, "td out of range");
+    if (!c->h_table_set[td]) return fail(FSPANN_E_STATE, "table %d not set", td);
+    if (n_parts) *n_parts = static_cast<int64_t>(c->h_min[td].size());
+    if (n_ids) *n_ids = static_cast<int64_t>(c->h_ids[td].size());
+    return FSPANN_OK;
+}
+
+int fspann_get_index(fspann_ctx* c, int td, int64_t* min_key, int64_t* max_key, uint64_t* rep, int64_t* id_off,
+                     int32_t* ids) {
+    CHECK_CTX(c);
+    if (td < 0 || td >= c->TD) return fail(FSPANN_E_ARG, "td out of range");
+    if (!c->h_table_set[td]) return fail(FSPANN_E_STATE, "table %d not set", td);
+    std::copy(c->h_min[td].begin(), c->h_min[td].end(), min_key);
+    std::copy(c->h_max[td].begin(), c->h_max[td].end(), max_key);
+    std::copy(c->h_rep[td].begin(), c->h_rep[td].end(), rep);
+    std::copy(c->h_off[td].begin(), c->h_off[td].end(), id_off);
+    std::copy(c->h_ids[td].begin(), c->h_ids[td].end(), ids);
+    return FSPANN_OK;
+}
+
+// ---- encode -----------------------------------------------------------------------
+int fspann_encode_dev(fspann_ctx* c, int64_t nq, const void* q_dev, int dtype, uint64_t* codes_dev,
+                      int32_t* hashes_dev, int32_t* bad_dev) {
+    CHECK_CTX(c);
+    if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized. Build index first.");
+    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    if (nq == 0) return FSPANN_OK;
+    if (!q_dev || !codes_dev) return fail(FSPANN_E_NULL, "query vector is null");
+    if (dtype == FSPANN_F64) return launch_encode<double>(c, nq, static_cast<const double*>(q_dev), codes_dev, hashes_dev, bad_dev);
+    if (dtype == FSPANN_F32) return launch_encode<float>(c, nq, static_cast<const float*>(q_dev), codes_dev, hashes_dev, bad_dev);
+    return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+}
+
+int fspann_encode(fspann_ctx* c, int64_t nq, const void* q, int dtype, uint64_t* codes, int32_t* hashes) {
+    CHECK_CTX(c);
+    if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized. Build index first.");
+    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    if (nq == 0) return FSPANN_OK;
+    if (!q || !codes) return fail(FSPANN_E_NULL, "query vector is null");
+    if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+    const size_t esz = dtype == FSPANN_F64 ? 8 : 4;
+    const size_t qb = static_cast<size_t>(nq) * c->cfg.dim * esz;
+    const size_t cb = static_cast<size_t>(nq) * c->TD * c->W * 8;
+    const size_t hb = hashes ? static_cast<size_t>(nq) * c->P_total * 4 : 0;
+    int rc;
+    if ((rc = ensure(c, c->ws_io[0], qb))) return rc;
+    if ((rc = ensure(c, c->ws_io[1], cb))) return rc;
+    if ((rc = ensure(c, c->ws_io[2], static_cast<size_t>(nq) * 4))) return rc;
+    if (hashes && (rc = ensure(c, c->ws_io[3], hb))) return rc;
+    FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, q, qb, hipMemcpyHostToDevice, c->stream));
+    rc = fspann_encode_dev(c, nq, c->ws_io[0].p, dtype, static_cast<uint64_t*>(c->ws_io[1].p),
+                           hashes ? static_cast<int32_t*>(c->ws_io[3].p) : nullptr, static_cast<int32_t*>(c->ws_io[2].p));
+    if (rc) return rc;
+    std::vector<int32_t> bad(static_cast<size_t>(nq));
+    FSP_HIP(hipMemcpyAsync(codes, c->ws_io[1].p, cb, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipMemcpyAsync(bad.data(), c->ws_io[2].p, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (hashes) FSP_HIP(hipMemcpyAsync(hashes, c->ws_io[3].p, hb, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < nq; i++)
+        if (bad[i]) return fail(FSPANN_E_ARG, "Vector contains NaN/Inf (query %lld)", (long long)i);  // Coding.java:360
+    return FSPANN_OK;
+}
+
+// ---- route --------------------------------------------------------------------------
+int fspann_effective_probes(fspann_ctx* c, int probe_override) { return c ? effective_probes(c, probe_override) : FSPANN_E_NULL; }
+
+int64_t fspann_route_max_candidates(fspann_ctx* c, int probe_override) {
+    if (!c) return FSPANN_E_NULL;
+    const int64_t mt = static_cast<int64_t>(c->TD) * effective_probes(c, probe_override) * c->cfg.block_size;
+    return std::min<int64_t>(mt, static_cast<int64_t>(c->hard_cap) - 1 + c->cfg.block_size);
+}
+
+int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit,
+                     int64_t cap, int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev,
+                     int32_t* raw_seen_dev) {
+    CHECK_CTX(c);
+    if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");  // PIS:594
+    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    if (nq == 0) return FSPANN_OK;
+    if (!codes_dev) return fail(FSPANN_E_STATE, "MSANNP violation: QueryToken missing BitSet codes");  // PIS:602
+    if (!ids_dev || !count_dev) return fail(FSPANN_E_NULL, "output buffer is null");
+    if (limit <= 0) return fail(FSPANN_E_ARG, "limit must be > 0");
+    RoutePlan pl;
+    int rc = plan_route(c, probe_override, nq, pl);
+    if (rc) return rc;
+    const int64_t need = std::min<int64_t>(limit, pl.maxcand);
+    if (cap < need) return fail(FSPANN_E_RANGE, "cap %lld < min(limit, worst case) = %lld", (long long)cap, (long long)need);
+    size_t gbytes = 0;
+    const size_t ht_g = pl.use_lds_ht ? 0 : static_cast<size_t>(pl.grid) * 2 * pl.ht_size * 4;
+    const size_t so_g = static_cast<size_t>(pl.grid) * pl.g_sort_stride * 8;
+    gbytes = ht_g + so_g;
+    if (gbytes && (rc = ensure(c, c->ws_route, gbytes + 64))) return rc;
+    RouteParams p{};
+    p.codes = codes_dev; p.tables = c->d_tables; p.keys2 = c->d_keys2; p.rep = c->d_rep; p.id_off = c->d_off; p.ids = c->d_ids;
+    p.java_hash = c->d_java_hash; p.deleted_bits = c->d_deleted_bits;
+    p.nq = nq; p.TD = c->TD; p.W = c->W; p.P = pl.P; p.S = pl.S;
+    p.hard_cap = c->hard_cap; p.cap0 = c->cap0; p.limit = limit; p.nbins = pl.nbins;
+    p.ht_size = pl.ht_size; p.ht_shift = pl.ht_shift; p.sort_cap_lds = pl.sort_cap_lds; p.max_tuples = pl.max_tuples;
+    p.use_lds_ht = pl.use_lds_ht;
+    p.g_sort = so_g ? static_cast<uint64_t*>(c->ws_route.p) : nullptr;
+    p.g_sort_stride = pl.g_sort_stride;
+    p.g_ht = ht_g ? reinterpret_cast<uint32_t*>(static_cast<char*>(c->ws_route.p) + so_g) : nullptr;
+    p.out_cap = cap; p.out_ids = ids_dev; p.out_score = score_dev; p.out_count = count_dev; p.out_kept = kept_dev; p.out_raw = raw_seen_dev;
+    if (pl.use_lds_ht) {
+        auto kern = route_kernel<true>;
+        FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds_bytes)));
+        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, c->stream, p);
+    } else {
+        auto kern = route_kernel<false>;
+        FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds_bytes)));
+        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, c->stream, p);
+    }
+    FSP_HIP(hipGetLastError());
+    return FSPANN_OK;
+}
+
+int fspann_route(fspann_ctx* c, int64_t nq, const uint64_t* codes, int probe_override, int32_t limit, int64_t cap,
+                 int32_t* ids, int32_t* score, int32_t* count, int32_t* kept, int32_t* raw_seen) {
+    CHECK_CTX(c);
+    if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
+    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    if (nq == 0) return FSPANN_OK;
+    if (!codes) return fail(FSPANN_E_STATE, "MSANNP violation: QueryToken missing BitSet codes");
+    if (!ids || !count) return fail(FSPANN_E_NULL, "output buffer is null");
+    const size_t cb = static_cast<size_t>(nq) * c->TD * c->W * 8;
+    const size_t ob = static_cast<size_t>(nq) * cap * 4;
+    int rc;
+    if ((rc = ensure(c, c->ws_io[0], cb))) return rc;
+    if ((rc = ensure(c, c->ws_io[1], ob))) return rc;
+    if ((rc = ensure(c, c->ws_io[2], ob))) return rc;
+    if ((rc = ensure(c, c->ws_io[3], static_cast<size_t>(nq) * 12))) return rc;
+    int32_t* cnt = static_cast<int32_t*>(c->ws_io[3].p);
+    FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, codes, cb, hipMemcpyHostToDevice, c->stream));
+    rc = fspann_route_dev(c, nq, static_cast<const uint64_t*>(c->ws_io[0].p), probe_override, limit, cap,
+                          static_cast<int32_t*>(c->ws_io[1].p), static_cast<int32_t*>(c->ws_io[2].p), cnt, cnt + nq, cnt + 2 * nq);
+    if (rc) return rc;
+    FSP_HIP(hipMemcpyAsync(ids, c->ws_io[1].p, ob, hipMemcpyDeviceToHost, c->stream));
+    if (score) FSP_HIP(hipMemcpyAsync(score, c->ws_io[2].p, ob, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipMemcpyAsync(count, cnt, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (kept) FSP_HIP(hipMemcpyAsync(kept, cnt + nq, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (raw_seen) FSP_HIP(hipMemcpyAsync(raw_seen, cnt + 2 * nq, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    return FSPANN_OK;
+}
+
+// ---- refine ---------------------------------------------------------------------------
+int fspann_refine_dev(fspann_ctx* c, int64_t nq, const void* q_dev, int q_dtype, const void* cand_dev, int cand_dtype,
+                      int64_t B, const int32_t* cand_ids_dev, const int32_t* cand_count_dev, int k, int32_t* out_ids_dev,
+                      double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev) {
+    CHECK_CTX(c);
+    if (nq < 0 || B <= 0) return fail(FSPANN_E_ARG, "nq < 0 or B <= 0");
+    if (k <= 0) return fail(FSPANN_E_ARG, "topK must be > 0");  // QueryTokenFactory.java:65
+    if (nq == 0) return FSPANN_OK;
+    if (!q_dev || !cand_dev || !cand_ids_dev || !cand_count_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)
+        return fail(FSPANN_E_NULL, "refine buffer is null");
+    if (static_cast<int64_t>(c->cfg.dim) * 8 > 96 * 1024) return fail(FSPANN_E_RANGE, "dim too large for the LDS query tile");
+#define FSP_REF(TC, TQ)                                                                                          \
+    return launch_refine_t<TC, TQ>(c, nq, static_cast<const TQ*>(q_dev), static_cast<const TC*>(cand_dev), B,    \
+                                   cand_ids_dev, cand_count_dev, k, out_ids_dev, out_dist_dev, out_count_dev,    \
+                                   scored_dev)
+    if (cand_dtype == FSPANN_F32 && q_dtype == FSPANN_F32) FSP_REF(float, float);
+    if (cand_dtype == FSPANN_F32 && q_dtype == FSPANN_F64) FSP_REF(float, double);
+    if (cand_dtype == FSPANN_F64 && q_dtype == FSPANN_F32) FSP_REF(double, float);
+    if (cand_dtype == FSPANN_F64 && q_dtype == FSPANN_F64) FSP_REF(double, double);
+#undef FSP_REF
+    return fail(FSPANN_E_ARG, "unknown dtype");
+}
+
+int fspann_refine(fspann_ctx* c, int64_t nq, const void* q, const void* cand, int dtype, int64_t B,
+                  const int32_t* cand_ids, const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist,
+                  int32_t* out_count, int32_t* scored) {
+    CHECK_CTX(c);
+    if (nq < 0 || B <= 0) return fail(FSPANN_E_ARG, "nq < 0 or B <= 0");
+    if (k <= 0) return fail(FSPANN_E_ARG, "topK must be > 0");
+    if (nq == 0) return FSPANN_OK;
+    if (!q || !cand || !cand_ids || !cand_count || !out_ids || !out_dist || !out_count) return fail(FSPANN_E_NULL, "refine buffer is null");
+    if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+    const size_t esz = dtype == FSPANN_F64 ? 8 : 4;
+    const int d = c->cfg.dim;
+    const size_t qb = static_cast<size_t>(nq) * d * esz, cb = static_cast<size_t>(nq) * B * d * esz;
+    const size_t ib = static_cast<size_t>(nq) * B * 4, nb = static_cast<size_t>(nq) * 4;
+    const size_t ob_i = static_cast<size_t>(nq) * k * 4, ob_d = static_cast<size_t>(nq) * k * 8;
+    int rc;
+    if ((rc = ensure(c, c->ws_io[0], qb))) return rc;
+    if ((rc = ensure(c, c->ws_io[1], cb))) return rc;
+    if ((rc = ensure(c, c->ws_io[2], ib))) return rc;
+    if ((rc = ensure(c, c->ws_io[3], nb * 3))) return rc;
+    if ((rc = ensure(c, c->ws_io[4], ob_i))) return rc;
+    if ((rc = ensure(c, c->ws_io[5], ob_d))) return rc;
+    int32_t* cnts = static_cast<int32_t*>(c->ws_io[3].p);
+    FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, q, qb, hipMemcpyHostToDevice, c->stream));
+    FSP_HIP(hipMemcpyAsync(c->ws_io[1].p, cand, cb, hipMemcpyHostToDevice, c->stream));
+    FSP_HIP(hipMemcpyAsync(c->ws_io[2].p, cand_ids, ib, hipMemcpyHostToDevice, c->stream));
+    FSP_HIP(hipMemcpyAsync(cnts, cand_count, nb, hipMemcpyHostToDevice, c->stream));
+    rc = fspann_refine_dev(c, nq, c->ws_io[0].p, dtype, c->ws_io[1].p, dtype, B, static_cast<int32_t*>(c->ws_io[2].p), cnts, k,
+                           static_cast<int32_t*>(c->ws_io[4].p), static_cast<double*>(c->ws_io[5].p), cnts + nq, cnts + 2 * nq);
+    if (rc) return rc;
+    FSP_HIP(hipMemcpyAsync(out_ids, c->ws_io[4].p, ob_i, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipMemcpyAsync(out_dist, c->ws_io[5].p, ob_d, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipMemcpyAsync(out_count, cnts + nq, nb, hipMemcpyDeviceToHost, c->stream));
+    if (scored) FSP_HIP(hipMemcpyAsync(scored, cnts + 2 * nq, nb, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    return FSPANN_OK;
+}
+
+// ---- plaintext store (test / bench harness) ----------------------------------------------
+int fspann_store_set(fspann_ctx* c, int64_t n, const void* vectors, int dtype) {
+    CHECK_CTX(c);
+    if (!vectors) return fail(FSPANN_E_NULL, "vectors is null");
+    if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
+    if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+    const size_t bytes = static_cast<size_t>(n) * c->cfg.dim * (dtype == FSPANN_F64 ? 8 : 4);
+    free_dev(c->d_store);
+    FSP_HIP(hipMalloc(&c->d_store, bytes));
+    FSP_HIP(hipMemcpy(c->d_store, vectors, bytes, hipMemcpyHostToDevice));
+    c->store_dtype = dtype;
+    c->store_n = n;
+    return FSPANN_OK;
+}
+
+const void* fspann_store_dev_ptr(fspann_ctx* c, int* dtype) {
+    if (!c) return nullptr;
+    if (dtype) *dtype = c->store_dtype;
+    return c->d_store;
+}
+
+int fspann_store_gather_dev(fspann_ctx* c, int64_t nq, const int32_t* sel_ids_dev, const int32_t* sel_count_dev, int64_t B,
+                            void* cand_dev) {
+    CHECK_CTX(c);
+    if (!c->d_store) return fail(FSPANN_E_STATE, "plaintext store not set");
+    if (!sel_ids_dev || !sel_count_dev || !cand_dev) return fail(FSPANN_E_NULL, "gather buffer is null");
+    if (nq <= 0 || B <= 0) return FSPANN_OK;
+    const int d = c->cfg.dim;
+    const int64_t rows = nq * B;
+    const unsigned grid = static_cast<unsigned>((rows + 7) / 8);
+    if (c->store_dtype == FSPANN_F32) {
+        const int vec_ok = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(cand_dev) & 15) == 0);
+        hipLaunchKernelGGL(store_gather_kernel<float>, dim3(grid), dim3(256), 0, c->stream, static_cast<const float*>(c->d_store), d,
+                           sel_ids_dev, sel_count_dev, B, nq, static_cast<float*>(cand_dev), vec_ok);
+    } else {
+        const int vec_ok = (d % 2 == 0) && ((reinterpret_cast<uintptr_t>(cand_dev) & 15) == 0);
+        hipLaunchKernelGGL(store_gather_kernel<double>, dim3(grid), dim3(256), 0, c->stream, static_cast<const double*>(c->d_store), d,
+                           sel_ids_dev, sel_count_dev, B, nq, static_cast<double*>(cand_dev), vec_ok);
+    }
+    FSP_HIP(hipGetLastError());
+    return FSPANN_OK;
+}
+
+// ---- device memory helpers -----------------------------------------------------------------
+int fspann_dev_alloc(fspann_ctx* c, size_t bytes, void** out) {
+    CHECK_CTX(c);
+    if (!out) return fail(FSPANN_E_NULL, "out is null");
+    FSP_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return FSPANN_OK;
+}
+int fspann_dev_free(fspann_ctx* c, void* p) {
+    CHECK_CTX(c);
+    if (p) {
+        FSP_HIP(hipStreamSynchronize(c->stream));
+        FSP_HIP(hipFree(p));
+    }
+    return FSPANN_OK;
+}
+int fspann_h2d(fspann_ctx* c, void* dst_dev, const void* src, size_t bytes) {
+    CHECK_CTX(c);
+    FSP_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, c->stream));
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    return FSPANN_OK;
+}
+int fspann_d2h(fspann_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+    CHECK_CTX(c);
+    FSP_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    return FSPANN_OK;
+}
+
+// ---- native Setup: code all vectors on the GPU, cut partitions -----------------------------
+// Replaces PIS.insert's coding loop (PIS:331-346) + PIS.build (PIS:372-434) +
+// GreedyPartitioner.build (idx/GreedyPartitioner.java:37-76).  The reference iterates a
+// HashMap<String,BitSet>(staged.size()) and stable-sorts by key, so elements with equal keys keep
+// HashMap iteration order = (bucket at the final capacity, insertion order) — the closed form used
+// here (valid while no bin treeifies; DESIGN.md "Java order key").
+int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype, const int32_t* order) {
+    CHECK_CTX(c);
+    if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized");
+    if (!vectors) return fail(FSPANN_E_NULL, "vector cannot be null");
+    if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
+    if (c->n_ids < n) return fail(FSPANN_E_STATE, "set id metadata for at least n handles first");
+    if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+    const int d = c->cfg.dim, TD = c->TD, W = c->W, S = c->cfg.block_size;
+    const size_t esz = dtype == FSPANN_F64 ? 8 : 4;
+    std::vector<int32_t> ord(static_cast<size_t>(n));
+    if (order) {
+        std::copy(order, order + n, ord.begin());
+        for (int64_t i = 0; i < n; i++)
+            if (ord[i] < 0 || ord[i] >= c->n_ids) return fail(FSPANN_E_ARG, "order[%lld] out of range", (long long)i);
+    } else {  // first MIN_SAMPLE_SIZE-1 inserts are parked and flushed at finalize
+        const int64_t ms = 1000;
+        int64_t k = 0;
+        if (n < ms) { for (int64_t i = 0; i < n; i++) ord[k++] = static_cast<int32_t>(i); }
+        else {
+            for (int64_t i = ms - 1; i < n; i++) ord[k++] = static_cast<int32_t>(i);
+            for (int64_t i = 0; i < ms - 1; i++) ord[k++] = static_cast<int32_t>(i);
+        }
+    }
+    // 1) codes for every handle (row h of `vectors`), in chunks
+    std::vector<uint64_t> codes(static_cast<size_t>(n) * TD * W);
+    const int64_t chunk = 1 << 18;
+    int rc;
+    if ((rc = ensure(c, c->ws_io[0], static_cast<size_t>(std::min(chunk, n)) * d * esz))) return rc;
+    if ((rc = ensure(c, c->ws_io[1], static_cast<size_t>(std::min(chunk, n)) * TD * W * 8))) return rc;
+    if ((rc = ensure(c, c->ws_io[2], static_cast<size_t>(std::min(chunk, n)) * 4))) return rc;
+    std::vector<int32_t> bad(static_cast<size_t>(std::min(chunk, n)));
+    for (int64_t s = 0; s < n; s += chunk) {
+        const int64_t cn = std::min(chunk, n - s);
+        FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, static_cast<const char*>(vectors) + static_cast<size_t>(s) * d * esz,
+                               static_cast<size_t>(cn) * d * esz, hipMemcpyHostToDevice, c->stream));
+        rc = fspann_encode_dev(c, cn, c->ws_io[0].p, dtype, static_cast<uint64_t*>(c->ws_io[1].p), nullptr,
+                               static_cast<int32_t*>(c->ws_io[2].p));
+        if (rc) return rc;
+        FSP_HIP(hipMemcpyAsync(codes.data() + static_cast<size_t>(s) * TD * W, c->ws_io[1].p, static_cast<size_t>(cn) * TD * W * 8,
+                               hipMemcpyDeviceToHost, c->stream));
+        FSP_HIP(hipMemcpyAsync(bad.data(), c->ws_io[2].p, static_cast<size_t>(cn) * 4, hipMemcpyDeviceToHost, c->stream));
+        FSP_HIP(hipStreamSynchronize(c->stream));
+        for (int64_t i = 0; i < cn; i++)
+            if (bad[i]) return fail(FSPANN_E_ARG, "Vector contains NaN/Inf (handle %lld)", (long long)(s + i));
+    }
+    // 2) per table: order by (key, HashMap bucket, insertion position), cut blocks of S
+    const int capf = java_final_cap_host(table_size_for(static_cast<int>(std::min<int64_t>(n, 1 << 30))), n);
+    std::vector<uint32_t> bucket(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; i++) {
+        uint32_t h = static_cast<uint32_t>(c->h_java_hash[ord[i]]);
+        h ^= (h >> 16);
+        bucket[i] = h & static_cast<uint32_t>(capf - 1);
+    }
+    struct Ent { int64_t key; uint32_t bucket; int32_t pos; };
+    std::vector<Ent> ents(static_cast<size_t>(n));
+    for (int td = 0; td < TD; td++) {
+        for (int64_t i = 0; i < n; i++) {
+            const uint64_t w0 = codes[(static_cast<size_t>(ord[i]) * TD + td) * W];
+            // computeKey: code bit i -> key bit 62-i for i < 63
+            uint64_t rev = 0;
+            uint64_t x = w0;
+            for (int b = 0; b < 64; b++) { rev = (rev << 1) | (x & 1); x >>= 1; }
+            ents[i] = {static_cast<int64_t>(rev >> 1), bucket[i], static_cast<int32_t>(i)};
+        }
+        std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) {
+            if (a.key != b.key) return a.key < b.key;
+            if (a.bucket != b.bucket) return a.bucket < b.bucket;
+            return a.pos < b.pos;
+        });
+        const int64_t np = (n + S - 1) / S;
+        auto& mn = c->h_min[td]; auto& mx = c->h_max[td]; auto& rp = c->h_rep[td]; auto& of = c->h_off[td]; auto& ii = c->h_ids[td];
+        mn.resize(np); mx.resize(np); rp.resize(static_cast<size_t>(np) * W); of.resize(np + 1); ii.resize(n);
+        for (int64_t p = 0; p < np; p++) {
+            const int64_t i0 = p * S, i1 = std::min<int64_t>(i0 + S, n);
+            mn[p] = ents[i0].key;
+            mx[p] = ents[i1 - 1].key;
+            const int64_t mid = i0 + ((i1 - i0 - 1) >> 1);
+            const int32_t rh = ord[ents[mid].pos];
+            for (int w = 0; w < W; w++) rp[static_cast<size_t>(p) * W + w] = codes[(static_cast<size_t>(rh) * TD + td) * W + w];
+            of[p] = i0;
+            for (int64_t i = i0; i < i1; i++) ii[i] = ord[ents[i].pos];
+        }
+        of[np] = n;
+        c->h_table_set[td] = 1;
+    }
+    c->dev_index_dirty = true;
+    return fspann_finalize(c);
+}
+
+}  // extern "C"

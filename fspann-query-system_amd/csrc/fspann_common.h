@@ -1,0 +1,152 @@
+// fspann_common.h — context, error plumbing and small helpers shared by the
+// gfx950 kernels and the C ABI (include/fspann.h).  Product code: never includes
+// or links anything under oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fspann.h"
+
+namespace fspann {
+
+// ---- thread-local error message ------------------------------------------------
+inline std::string& last_error_ref() {
+    static thread_local std::string s;
+    return s;
+}
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+#define FSP_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return ::fspann::fail(_e == hipErrorOutOfMemory ? FSPANN_E_NOMEM : FSPANN_E_DEVICE,    \
+                                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                                  __LINE__);                                                       \
+    } while (0)
+
+// ---- order-key bit budget (DESIGN.md "Java order key") ----------------------------
+// key = score(10) | bucket(20) | seq(22); seq = (td*P + step)*S + pos is unique per tuple.
+constexpr int kSeqBits = 22;
+constexpr int kBucketBits = 20;
+constexpr int kScoreBits = 10;
+constexpr uint32_t kSeqMask = (1u << kSeqBits) - 1;
+constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+
+// One (t,d) table inside the concatenated device arrays.
+struct RouteTable {
+    int64_t part_base;  // first partition of this table in keys2 / rep
+    int64_t off_base;   // first entry of this table in id_off (nparts+1 entries per table)
+    int64_t ids_base;   // first id of this table in ids
+    int32_t nparts;
+    int32_t pad;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace fspann
+
+// The opaque context of include/fspann.h.
+struct fspann_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    fspann_cfg cfg{};
+    int TD = 0, W = 0, bits = 0, P_total = 0;  // P_total = TD*m projections
+    int hard_cap = 0;                          // max(maxGlobalCandidates, refinementLimit), PIS:612-615
+    int cap0 = 0;                              // tableSizeFor(min(HARD_CAP, 1<<16)), PIS:619
+    int num_cus = 256;
+    int lds_limit = 160 * 1024;
+    bool frozen = false;
+    bool have_g = false;
+
+    // GFunctions: alphaT[dim][P_total] fp64 (transposed for coalescing), r/omega[P_total]
+    double* d_alphaT = nullptr;
+    double* d_r = nullptr;
+    double* d_omega = nullptr;
+    std::vector<double> h_alpha, h_r, h_omega;  // host copies (export)
+
+    // frozen index (concatenated over td)
+    std::vector<fspann::RouteTable> h_tables;
+    std::vector<std::vector<int64_t>> h_min, h_max, h_off;  // host mirror per td (export / rebuild)
+    std::vector<std::vector<uint64_t>> h_rep;
+    std::vector<std::vector<int32_t>> h_ids;
+    std::vector<char> h_table_set;
+    bool dev_index_dirty = true;
+    fspann::RouteTable* d_tables = nullptr;
+    int64_t* d_keys2 = nullptr;   // [total_parts][2] {min,max}
+    uint64_t* d_rep = nullptr;    // [total_parts][W]
+    int32_t* d_off = nullptr;     // per table nparts+1 entries, relative to ids_base
+    int32_t* d_ids = nullptr;
+    int64_t total_parts = 0, total_ids = 0;
+
+    // id metadata
+    int64_t n_ids = 0;
+    int32_t* d_java_hash = nullptr;
+    uint32_t* d_deleted_bits = nullptr;  // nullptr => nothing deleted
+    std::vector<int32_t> h_java_hash;
+
+    // plaintext store (test / bench harness)
+    void* d_store = nullptr;
+    int store_dtype = FSPANN_F32;
+    int64_t store_n = 0;
+
+    // scratch arenas (grown on demand, reused across calls)
+    fspann::DevBuf ws_route;   // global hash/sort fallback for the route kernel
+    fspann::DevBuf ws_refine;  // per-chunk partial top-k
+    fspann::DevBuf ws_io[8];   // staging for the host-pointer entry points
+};
+
+namespace fspann {
+
+inline int ensure(fspann_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return FSPANN_OK;
+    if (b.p) {
+        FSP_HIP(hipStreamSynchronize(c->stream));
+        FSP_HIP(hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    FSP_HIP(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return FSPANN_OK;
+}
+
+// java.util.HashMap.tableSizeFor
+inline int table_size_for(int cap) {
+    uint32_t c = static_cast<uint32_t>(cap - 1);
+    int nlz = (c == 0) ? 32 : __builtin_clz(c);
+    int32_t n = static_cast<int32_t>(0xFFFFFFFFu >> (nlz & 31));
+    if (n < 0) return 1;
+    if (n >= (1 << 30)) return 1 << 30;
+    return n + 1;
+}
+
+// String.hashCode of Long.toString(v) (ids are decimal ordinals, ForwardSecureANNSystem.java:515)
+inline int32_t decimal_string_hash(int64_t v) {
+    char buf[24];
+    int n = snprintf(buf, sizeof(buf), "%lld", static_cast<long long>(v));
+    uint32_t h = 0;
+    for (int i = 0; i < n; i++) h = 31u * h + static_cast<unsigned char>(buf[i]);
+    return static_cast<int32_t>(h);
+}
+
+}  // namespace fspann

@@ -1,0 +1,233 @@
+"""FspannContext — numpy-facing wrapper of one `fspann_ctx` (one GPU, one HIP stream).
+
+Batch-first: every call takes nq >= 1 queries.  Host arrays go through the
+host-pointer entry points of include/fspann.h; `*_dev` methods take raw device
+pointers (ints, e.g. torch.Tensor.data_ptr()) and only enqueue work on the
+context's stream.  Product code — never imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+
+
+@dataclass
+class PaperRuntimeConfig:
+    """The nine knobs the path reads (config/SystemConfig.java:237-338)."""
+    tables: int = 6
+    divisions: int = 3
+    m: int = 24
+    lambda_: int = 2
+    dim: int = 128
+    seed: int = 13
+    refinement_limit: int = 20000
+    max_global_candidates: int = 20000
+    probe_override: int = -1
+    hamming_prefilter_threshold: int = 0
+    block_size: int = 64
+    default_probes: int = 5
+
+    def to_c(self) -> N.Cfg:
+        return N.Cfg(self.tables, self.divisions, self.m, self.lambda_, self.dim, self.block_size,
+                     self.default_probes, self.probe_override, self.max_global_candidates,
+                     self.refinement_limit, self.hamming_prefilter_threshold, 0)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dt(a):
+    if a.dtype == np.float32:
+        return N.F32
+    if a.dtype == np.float64:
+        return N.F64
+    raise N.FspannArgumentError(f"unsupported dtype {a.dtype}")
+
+
+class FspannContext:
+    def __init__(self, cfg: PaperRuntimeConfig, device: int = 0):
+        self.cfg = cfg
+        self.L = N.lib()
+        h = C.c_void_p()
+        cc = cfg.to_c()
+        N.check(self.L.fspann_ctx_create(device, C.byref(cc), C.byref(h)))
+        self._h = h
+        self.TD = cfg.tables * cfg.divisions
+        self.bits = cfg.m * cfg.lambda_
+        self.W = (self.bits + 63) // 64
+        self.hard_cap = max(cfg.max_global_candidates, cfg.refinement_limit)
+        self.device = device
+
+    # -- lifecycle -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.fspann_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self) -> int:
+        return int(self.L.fspann_ctx_stream(self._h) or 0)
+
+    def sync(self):
+        N.check(self.L.fspann_sync(self._h))
+
+    # -- Setup ---------------------------------------------------------------
+    def set_gfunctions(self, alpha, r, omega):
+        c = self.cfg
+        a = _c(alpha, np.float64).reshape(self.TD, c.m, c.dim)
+        rr = _c(r, np.float64).reshape(self.TD, c.m)
+        ww = _c(omega, np.float64).reshape(self.TD, c.m)
+        N.check(self.L.fspann_set_gfunctions(self._h, _p(a), _p(rr), _p(ww)))
+
+    def registry_initialize(self, sample, base_seed=None):
+        s = _c(sample, np.float64).reshape(-1, self.cfg.dim)
+        seed = self.cfg.seed if base_seed is None else base_seed
+        N.check(self.L.fspann_registry_initialize(self._h, _p(s), s.shape[0], seed))
+
+    def get_gfunctions(self):
+        c = self.cfg
+        a = np.empty((self.TD, c.m, c.dim), np.float64)
+        r = np.empty((self.TD, c.m), np.float64)
+        w = np.empty((self.TD, c.m), np.float64)
+        N.check(self.L.fspann_get_gfunctions(self._h, _p(a), _p(r), _p(w)))
+        return a, r, w
+
+    def set_id_meta(self, n_ids, java_hash=None, deleted=None):
+        jh = None if java_hash is None else _c(java_hash, np.int32)
+        dl = None if deleted is None else _c(deleted, np.uint8)
+        N.check(self.L.fspann_set_id_meta(self._h, n_ids, _p(jh), _p(dl)))
+        self.n_ids = n_ids
+
+    def set_index(self, td, min_key, max_key, rep, id_off, ids):
+        mn, mx = _c(min_key, np.int64), _c(max_key, np.int64)
+        rp, of, ii = _c(rep, np.uint64), _c(id_off, np.int64), _c(ids, np.int32)
+        N.check(self.L.fspann_set_index(self._h, td, len(mn), _p(mn), _p(mx), _p(rp), _p(of), _p(ii)))
+
+    def finalize(self):
+        N.check(self.L.fspann_finalize(self._h))
+
+    def build_index(self, vectors, order=None):
+        v = np.ascontiguousarray(vectors)
+        if v.dtype not in (np.float32, np.float64):
+            v = v.astype(np.float64)
+        v = v.reshape(-1, self.cfg.dim)
+        o = None if order is None else _c(order, np.int32)
+        N.check(self.L.fspann_build_index(self._h, v.shape[0], _p(v), _dt(v), _p(o)))
+
+    def get_index(self, td):
+        npart, nid = C.c_int64(), C.c_int64()
+        N.check(self.L.fspann_index_dims(self._h, td, C.byref(npart), C.byref(nid)))
+        mn = np.empty(npart.value, np.int64)
+        mx = np.empty(npart.value, np.int64)
+        rep = np.empty((npart.value, self.W), np.uint64)
+        off = np.empty(npart.value + 1, np.int64)
+        ids = np.empty(nid.value, np.int32)
+        N.check(self.L.fspann_get_index(self._h, td, _p(mn), _p(mx), _p(rep), _p(off), _p(ids)))
+        return dict(min_key=mn, max_key=mx, rep=rep, id_off=off, ids=ids)
+
+    # -- TokenGen ----------------------------------------------------------------
+    def encode(self, q, want_hashes=False):
+        if q is None:
+            raise N.FspannNullError("query vector is null")
+        q = np.ascontiguousarray(q)
+        if q.dtype not in (np.float32, np.float64):
+            q = q.astype(np.float64)
+        if q.size % self.cfg.dim != 0:
+            raise N.FspannArgumentError(f"Expected vector length {self.cfg.dim}")
+        q = q.reshape(-1, self.cfg.dim)
+        nq = q.shape[0]
+        codes = np.zeros((nq, self.TD, self.W), np.uint64)
+        hs = np.zeros((nq, self.TD, self.cfg.m), np.int32) if want_hashes else None
+        N.check(self.L.fspann_encode(self._h, nq, _p(q), _dt(q), _p(codes), _p(hs)))
+        return (codes, hs) if want_hashes else codes
+
+    # -- Route ---------------------------------------------------------------------
+    def effective_probes(self, probe_override=-1):
+        return self.L.fspann_effective_probes(self._h, probe_override)
+
+    def route_max_candidates(self, probe_override=-1):
+        return int(self.L.fspann_route_max_candidates(self._h, probe_override))
+
+    def route(self, codes, probe_override=-1, limit=N.INT32_MAX, cap=None):
+        if codes is None:
+            raise N.FspannStateError("MSANNP violation: QueryToken missing BitSet codes")
+        codes = _c(codes, np.uint64).reshape(-1, self.TD, self.W)
+        nq = codes.shape[0]
+        if cap is None:
+            cap = max(1, min(limit, self.route_max_candidates(probe_override)))
+        ids = np.full((nq, cap), -1, np.int32)
+        score = np.full((nq, cap), -1, np.int32)
+        count = np.zeros(nq, np.int32)
+        kept = np.zeros(nq, np.int32)
+        raw = np.zeros(nq, np.int32)
+        N.check(self.L.fspann_route(self._h, nq, _p(codes), probe_override, min(limit, N.INT32_MAX), cap, _p(ids),
+                                    _p(score), _p(count), _p(kept), _p(raw)))
+        return dict(ids=ids, score=score, count=count, kept=kept, raw_seen=raw)
+
+    # -- Refine ----------------------------------------------------------------------
+    def refine(self, q, cand, cand_ids, cand_count, k):
+        cand = np.ascontiguousarray(cand)
+        if cand.dtype not in (np.float32, np.float64):
+            cand = cand.astype(np.float64)
+        nq, B, d = cand.shape
+        q = _c(q, cand.dtype).reshape(nq, d)
+        ci = _c(cand_ids, np.int32).reshape(nq, B)
+        cc = _c(cand_count, np.int32).reshape(nq)
+        out_ids = np.empty((nq, k), np.int32)
+        out_dist = np.empty((nq, k), np.float64)
+        out_count = np.empty(nq, np.int32)
+        scored = np.empty(nq, np.int32)
+        N.check(self.L.fspann_refine(self._h, nq, _p(q), _p(cand), _dt(cand), B, _p(ci), _p(cc), k, _p(out_ids),
+                                     _p(out_dist), _p(out_count), _p(scored)))
+        return dict(ids=out_ids, dist=out_dist, count=out_count, scored=scored)
+
+    # -- plaintext store (test / bench harness) --------------------------------------
+    def store_set(self, vectors):
+        v = np.ascontiguousarray(vectors)
+        if v.dtype not in (np.float32, np.float64):
+            v = v.astype(np.float64)
+        v = v.reshape(-1, self.cfg.dim)
+        N.check(self.L.fspann_store_set(self._h, v.shape[0], _p(v), _dt(v)))
+        self.store_dtype = v.dtype
+
+    # -- device-pointer entry points (ints) ----------------------------------------------
+    def encode_dev(self, nq, q_ptr, dtype, codes_ptr, hashes_ptr=0, bad_ptr=0):
+        N.check(self.L.fspann_encode_dev(self._h, nq, q_ptr, dtype, codes_ptr, hashes_ptr or None, bad_ptr or None))
+
+    def route_dev(self, nq, codes_ptr, probe_override, limit, cap, ids_ptr, score_ptr, count_ptr, kept_ptr, raw_ptr):
+        N.check(self.L.fspann_route_dev(self._h, nq, codes_ptr, probe_override, limit, cap, ids_ptr, score_ptr or None,
+                                        count_ptr, kept_ptr or None, raw_ptr or None))
+
+    def store_gather_dev(self, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr):
+        N.check(self.L.fspann_store_gather_dev(self._h, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr))
+
+    def refine_dev(self, nq, q_ptr, q_dtype, cand_ptr, cand_dtype, B, cand_ids_ptr, cand_count_ptr, k, out_ids_ptr,
+                   out_dist_ptr, out_count_ptr, scored_ptr=0):
+        N.check(self.L.fspann_refine_dev(self._h, nq, q_ptr, q_dtype, cand_ptr, cand_dtype, B, cand_ids_ptr,
+                                         cand_count_ptr, k, out_ids_ptr, out_dist_ptr, out_count_ptr,
+                                         scored_ptr or None))

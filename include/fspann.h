@@ -1,0 +1,181 @@
+/* =============================================================================
+ * fspann.h — C ABI of libfspann_hip.so: MI355X-native (gfx950) TokenGen -> Route
+ * -> Refine for FSPANN.
+ *
+ * This is the drop-in boundary for the ONE hot path of
+ * Mehran-Memon/fspann-query-system.  The reference is pure Java with no FFI seam
+ * (constructor wiring, ForwardSecureANNSystem.java:316-322,362-398), so each entry
+ * point below names the reference method whose arithmetic it replaces; the JNI stub
+ * a maintainer adds is shown in INTEGRATION.md and jni/fspann_jni.cpp.
+ *
+ * Paths (under /root/reference/fsp-anns-parent/):
+ *   idx = index/src/main/java/com/fspann/index/paper
+ *   qry = query/src/main/java/com/fspann/query
+ *   PIS = idx/PartitionedIndexService.java      QSI = qry/service/QueryServiceImpl.java
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types cross this boundary.
+ *   - every call returns 0 (FSPANN_OK) or a negative error mapped 1:1 onto the Java
+ *     exception class the reference would throw; fspann_last_error() returns a
+ *     thread-local message.  No C++ exception crosses the ABI.
+ *   - buffers are caller-owned.  Functions WITHOUT the _dev suffix take host
+ *     pointers and copy in/out; functions WITH _dev take device (HBM) pointers and
+ *     only enqueue work on the context's HIP stream (fspann_ctx_stream); the caller
+ *     synchronises with fspann_sync() or its own stream/event calls.
+ *   - ids are int32 handles.  The Java adapter keeps String id <-> handle and
+ *     hands String.hashCode() per handle to fspann_set_id_meta (it decides the
+ *     reference's HashMap iteration order, see DESIGN.md "Java order key").
+ *   - one context = one GPU = one stream; calls on a context are serialised by
+ *     the caller (QueryServiceImpl is not re-entrant either, QSI:45-64).
+ * ========================================================================== */
+#ifndef FSPANN_H
+#define FSPANN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSPANN_OK 0
+#define FSPANN_E_STATE (-1)  /* java.lang.IllegalStateException   (PIS:594,602,605,630; QueryTokenFactory.java:67-88) */
+#define FSPANN_E_ARG (-2)    /* java.lang.IllegalArgumentException (Coding.java:355-361; QueryTokenFactory.java:65)  */
+#define FSPANN_E_NULL (-3)   /* java.lang.NullPointerException     (Objects.requireNonNull)                          */
+#define FSPANN_E_DEVICE (-4) /* HIP runtime failure                                                                   */
+#define FSPANN_E_NOMEM (-5)  /* allocation failure                                                                    */
+#define FSPANN_E_RANGE (-6)  /* a caller-provided capacity is too small                                               */
+
+#define FSPANN_F32 0
+#define FSPANN_F64 1
+
+typedef struct fspann_ctx fspann_ctx;
+
+/* paper.* and runtime.* knobs of config/SystemConfig.java:237-338 that the path reads. */
+typedef struct fspann_cfg {
+    int32_t tables;                 /* paper.tables   (T)                                   */
+    int32_t divisions;              /* paper.divisions (D)                                  */
+    int32_t m;                      /* paper.m        projections per GFunction             */
+    int32_t lambda;                 /* paper.lambda   bits per projection                   */
+    int32_t dim;                    /* vector dimension d                                   */
+    int32_t block_size;             /* PIS:92  DEFAULT_GREEDY_BLOCK_SIZE = 64 (0 => 64)     */
+    int32_t default_probes;         /* PIS:93  DEFAULT_MAX_PROBES = 5        (0 => 5)       */
+    int32_t probe_override;         /* runtime.probeOverride (<= 0: none), PIS:884-885      */
+    int32_t max_global_candidates;  /* runtime.maxGlobalCandidates (0 => 20000)             */
+    int32_t refinement_limit;       /* runtime.refinementLimit    (0 => 20000)              */
+    int32_t hamming_prefilter_threshold; /* runtime.hammingPrefilterThreshold (QSI:169)     */
+    int32_t reserved;
+} fspann_cfg;
+
+/* ---- lifecycle ----------------------------------------------------------------- */
+int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out);
+void fspann_ctx_destroy(fspann_ctx* ctx);
+const char* fspann_last_error(void);
+const char* fspann_version(void);
+/* hipStream_t of the context, as void* (for hipEvent timing / torch.cuda.ExternalStream). */
+void* fspann_ctx_stream(fspann_ctx* ctx);
+int fspann_sync(fspann_ctx* ctx);
+
+/* ---- Setup: import the frozen routing state ----------------------------------------
+ * Replaces the JVM-heap state of GFunctionRegistry (idx/GFunctionRegistry.java:63-147) and
+ * PIS.dims (PIS:60,96-113).  alpha[T*D][m][dim], r[T*D][m], omega[T*D][m], all fp64, exactly
+ * the Coding.GFunction fields (idx/Coding.java:52-97).  (t,d) is flattened td = t*D + d.   */
+int fspann_set_gfunctions(fspann_ctx* ctx, const double* alpha, const double* r, const double* omega);
+
+/* Native GFunctionRegistry.initialize (idx/GFunctionRegistry.java:63-147 -> Coding.buildFromSample,
+ * idx/Coding.java:184-241): sample = [ns][dim] fp64 (the reference passes the first 1000 inserted
+ * vectors, PIS:280-289); seed(t,d) = base_seed + t*1000003 + d.  alpha comes from Box-Muller on
+ * SplittableRandom with the platform libm, so it is self-consistent but NOT claimed equal to a
+ * JVM's alpha for the same seed — a Java caller imports its own with fspann_set_gfunctions.   */
+int fspann_registry_initialize(fspann_ctx* ctx, const double* sample, int64_t ns, int64_t base_seed);
+int fspann_get_gfunctions(fspann_ctx* ctx, double* alpha, double* r, double* omega);
+
+/* One (t,d) table of GreedyPartitioner.Partition (idx/GreedyPartitioner.java:13-32) as SoA:
+ * min_key/max_key[n_parts], rep[n_parts][W] (W = ceil(m*lambda/64) BitSet words, bit i ->
+ * word i/64 bit i%64), id_off[n_parts+1], ids[id_off[n_parts]] in partition order.          */
+int fspann_set_index(fspann_ctx* ctx, int td, int64_t n_parts, const int64_t* min_key, const int64_t* max_key,
+                     const uint64_t* rep, const int64_t* id_off, const int32_t* ids);
+
+/* java_hash[h] = String.hashCode() of the id behind handle h (NULL: ids are the decimal
+ * ordinals Long.toString(h), ForwardSecureANNSystem.java:515); deleted[h] != 0 mirrors
+ * metadata.isDeleted(id) (PIS:739; common/RocksDBMetadataManager.java:203-224); NULL: none. */
+int fspann_set_id_meta(fspann_ctx* ctx, int64_t n_ids, const int32_t* java_hash, const uint8_t* deleted);
+
+/* PIS.finalizeForSearch (PIS:789-845): freezes the context; Route calls before it fail
+ * with FSPANN_E_STATE ("Index not finalized", PIS:594).                                     */
+int fspann_finalize(fspann_ctx* ctx);
+
+/* Native Setup (replaces PIS.insert's coding loop PIS:331-346 + PIS.build
+ * PIS:372-434 + GreedyPartitioner.build): codes all n vectors on the GPU with the exact
+ * fp64 kernel and cuts partitions.  `order[n]` = handles in the order they reach `staged`
+ * (NULL: the stock pipeline's 999,1000,..,n-1,0,..,998).  vectors = [n][dim]
+ * host, row h = handle h.  Requires set_gfunctions + set_id_meta first.  Freezes ctx.     */
+int fspann_build_index(fspann_ctx* ctx, int64_t n, const void* vectors, int dtype, const int32_t* order);
+
+/* Export a built/imported table (sizes via fspann_index_dims). */
+int fspann_index_dims(fspann_ctx* ctx, int td, int64_t* n_parts, int64_t* n_ids);
+int fspann_get_index(fspann_ctx* ctx, int td, int64_t* min_key, int64_t* max_key, uint64_t* rep,
+                     int64_t* id_off, int32_t* ids);
+
+/* ---- TokenGen math: Coding.H + Coding.C for all T*D GFunctions ------------------------
+ * Replaces the loop QueryTokenFactory.create :98-131 (and PIS.insert :331-346).
+ * codes = [nq][T*D][W].  Exact: sequential fp64, no FMA == Java (idx/Coding.java:250-258,
+ * 285-301, 349-353).  NaN/Inf in a vector => FSPANN_E_ARG ("Vector contains NaN/Inf").
+ * hashes (optional, may be NULL) = [nq][T*D][m] int32 Coding.H values.                    */
+int fspann_encode(fspann_ctx* ctx, int64_t nq, const void* q, int dtype, uint64_t* codes, int32_t* hashes);
+int fspann_encode_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int dtype, uint64_t* codes_dev,
+                      int32_t* hashes_dev, int32_t* bad_dev /* [nq], 1 where NaN/Inf */);
+
+/* ---- Route: PIS.lookupCandidatesWithScores (PIS:592-715) ---------------------------
+ * codes = [nq][T*D][W].  probe_override > 0 overrides like PIS.setProbeOverride (PIS:868,
+ * 880-888).  Writes, per query, the first min(limit, kept) entries of the reference's result
+ * list (HashMap iteration order stable-sorted by score) into ids/score[nq][cap];
+ * count[q] = entries written, kept[q] = size of the full list (QSI.lastCandKept),
+ * raw_seen[q] = PIS.getLastRawCandidateCount().
+ *   limit = INT32_MAX       -> lookupCandidatesWithScores (full list)
+ *   limit = HARD_CAP        -> lookupCandidateIds (PIS:459-582, truncation :558-565)
+ *   limit = refinementLimit -> QSI stage A.5 (QSI:169-214), F_q
+ * cap < min(limit, worst case) => FSPANN_E_RANGE.                                          */
+int fspann_route(fspann_ctx* ctx, int64_t nq, const uint64_t* codes, int probe_override, int32_t limit,
+                 int64_t cap, int32_t* ids, int32_t* score, int32_t* count, int32_t* kept, int32_t* raw_seen);
+int fspann_route_dev(fspann_ctx* ctx, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit,
+                     int64_t cap, int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev,
+                     int32_t* raw_seen_dev);
+/* Worst-case entries per query for (probes): min(T*D*probes*block_size, HARD_CAP + block_size - 1). */
+int64_t fspann_route_max_candidates(fspann_ctx* ctx, int probe_override);
+int fspann_effective_probes(fspann_ctx* ctx, int probe_override); /* PIS:880-888 */
+
+/* ---- Refine: QSI stage B (distance part) + stage C ------------------------------------
+ * Replaces QSI.l2 (QSI:364-372), isValid (:407-413), the stable sort + top-K (:298-316).
+ * q = [nq][dim]; cand = [nq][B][dim] packed decrypted candidates (row j < cand_count[q] valid,
+ * in F_q order; rows the host could not load/decrypt are simply absent); cand_ids[nq][B].
+ * Distances are sequential fp64 like Java (bit-exact when inputs are exactly representable,
+ * always <= 1e-5 relative).  Non-finite candidate rows are skipped; a non-finite query gives
+ * out_count = 0.  out_ids/out_dist = [nq][k], padded with -1 / +inf; out_count[q] =
+ * min(k, scored); scored[q] (optional) = QSI.lastCandDecrypted.                            */
+int fspann_refine(fspann_ctx* ctx, int64_t nq, const void* q, const void* cand, int dtype, int64_t B,
+                  const int32_t* cand_ids, const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist,
+                  int32_t* out_count, int32_t* scored);
+int fspann_refine_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtype, const void* cand_dev,
+                      int cand_dtype, int64_t B, const int32_t* cand_ids_dev, const int32_t* cand_count_dev, int k,
+                      int32_t* out_ids_dev, double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev);
+
+/* ---- plaintext store (TEST / BENCH harness only) ----------------------------------------
+ * Stand-in for the host's loadPointIfActive + decryptFromPoint (PIS:717-724;
+ * crypto/AesGcmCryptoService.java:126-166), which stay on the host in production: keeps
+ * plaintext rows in HBM and packs F_q rows into the [nq][B][dim] buffer Refine consumes.   */
+int fspann_store_set(fspann_ctx* ctx, int64_t n, const void* vectors, int dtype /* stored as given */);
+int fspann_store_gather_dev(fspann_ctx* ctx, int64_t nq, const int32_t* sel_ids_dev, const int32_t* sel_count_dev,
+                            int64_t B, void* cand_dev /* [nq][B][dim], store dtype */);
+const void* fspann_store_dev_ptr(fspann_ctx* ctx, int* dtype);
+
+/* ---- device memory helpers (so non-torch callers can own HBM buffers) ------------------- */
+int fspann_dev_alloc(fspann_ctx* ctx, size_t bytes, void** out);
+int fspann_dev_free(fspann_ctx* ctx, void* p);
+int fspann_h2d(fspann_ctx* ctx, void* dst_dev, const void* src, size_t bytes);
+int fspann_d2h(fspann_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSPANN_H */
