@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job queries/s of the TokenGen -> Route -> Refine hot path on N MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from env).
+One "step" = one pass of the hot path over one batch of `--batch` queries PER GPU
+(weak scaling: the index is replicated, query batches shard embarrassingly):
+
+    encode (exact fp64 Coding.H/C)  ->  route (probe + dedupe + Java-order select-B)
+    -> candidate staging (device gather from a plaintext store: stand-in for the host's
+       load + AES-GCM decrypt, which stay on the host in production)
+    -> refine (sequential-fp64 L2 scan + stable top-k)  [-> RCCL all-gather of top-k, N > 1]
+
+All inputs (queries, frozen index, plaintext store) are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.  Extra objects: `roofline` (refine scan, live HIP-event
+timing on the context's stream), `cpu_baseline` (the C++ oracle on this box's host cores,
+bounded sample), `stages_ms`, `recall_at_10`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: SIFT-1M-shaped, 16 tables x 32 bits (m=16, lambda=2, divisions=1), B=256, batch=1024
+    "sift1m_T16_b32_B256_Q1024": dict(n=1_000_000, d=128, T=16, D=1, m=16, lam=2, B=256, Q=1024, k=10),
+    # BASELINE.json configs[0]: plumbing case
+    "synth10k_T8_b16_B64_Q100": dict(n=10_000, d=128, T=8, D=1, m=8, lam=2, B=64, Q=100, k=10),
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="sift1m_T16_b32_B256_Q1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="queries timed on the CPU oracle")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = graft.load_package()
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch > 0:
+        wl["Q"] = args.batch
+    n, d, T, D, m, lam, B, Q, k = (wl[x] for x in ("n", "d", "T", "D", "m", "lam", "B", "Q", "k"))
+    TD, W = T * D, (m * lam + 63) // 64
+
+    # ---------------- synthetic data (same on every rank; queries differ per rank) ----------------
+    t0 = time.time()
+    rng = np.random.default_rng(args.seed)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    qrng = np.random.default_rng(args.seed + 1000 + rank)
+    Qh = qrng.standard_normal((Q, d), dtype=np.float32)
+    cfg = pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=lam, dim=d, seed=13, refinement_limit=B)
+    ctx = pkg.FspannContext(cfg, local_rank)
+    ctx.registry_initialize(X[:1000].astype(np.float64))   # GFunctionRegistry.initialize from the first 1000 vectors
+    ctx.set_id_meta(n)
+    ctx.build_index(X)                                      # GPU coding + partition cut
+    ctx.store_set(X)                                        # plaintext store (decrypt stand-in), fp32
+    if rank == 0:
+        log(f"[bench] setup {time.time() - t0:.1f}s: n={n} d={d} T*D={TD} bits={m * lam} B={B} Q/GPU={Q} k={k}")
+
+    # ---------------- device buffers ------------------------------------------------------------------
+    q_dev = torch.from_numpy(Qh).to(dev)
+    codes = torch.zeros((Q, TD, W), dtype=torch.int64, device=dev)
+    bad = torch.zeros(Q, dtype=torch.int32, device=dev)
+    sel_ids = torch.full((Q, B), -1, dtype=torch.int32, device=dev)
+    sel_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
+    kept = torch.zeros(Q, dtype=torch.int32, device=dev)
+    raw = torch.zeros(Q, dtype=torch.int32, device=dev)
+    cand = torch.zeros((Q, B, d), dtype=torch.float32, device=dev)
+    out_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
+    out_dist = torch.zeros((Q, k), dtype=torch.float64, device=dev)
+    out_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
+    scored = torch.zeros(Q, dtype=torch.int32, device=dev)
+    gathered = torch.zeros((world, Q, k, 2), dtype=torch.float64, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    F32 = pkg._native.F32
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    def step(events=None):
+        if events is not None:
+            events[0].record(stream)
+        ctx.encode_dev(Q, q_dev.data_ptr(), F32, codes.data_ptr(), 0, bad.data_ptr())
+        if events is not None:
+            events[1].record(stream)
+        ctx.route_dev(Q, codes.data_ptr(), -1, B, B, sel_ids.data_ptr(), 0, sel_cnt.data_ptr(), kept.data_ptr(), raw.data_ptr())
+        if events is not None:
+            events[2].record(stream)
+        ctx.store_gather_dev(Q, sel_ids.data_ptr(), sel_cnt.data_ptr(), B, cand.data_ptr())
+        if events is not None:
+            events[3].record(stream)
+        ctx.refine_dev(Q, q_dev.data_ptr(), F32, cand.data_ptr(), F32, B, sel_ids.data_ptr(), sel_cnt.data_ptr(), k,
+                       out_ids.data_ptr(), out_dist.data_ptr(), out_cnt.data_ptr(), scored.data_ptr())
+        if events is not None:
+            events[4].record(stream)
+        if world > 1:
+            # the one collective of the path: all-gather of [Q x k] (id, dist) per rank over RCCL/xGMI
+            with torch.cuda.stream(stream):
+                packed = torch.stack((out_ids.to(torch.float64), out_dist), dim=-1)
+                dist.all_gather_into_tensor(gathered.view(world * Q, k, 2), packed)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    evs = [[ev() for _ in range(5)] for _ in range(args.steps)]
+    barrier()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        step(evs[i])
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    stage_ms = np.array([[evs[i][j].elapsed_time(evs[i][j + 1]) for j in range(4)] for i in range(args.steps)])
+    st_mean = stage_ms.mean(axis=0)
+    ms_per_step = elapsed * 1000.0 / args.steps
+    qps = world * Q * args.steps / elapsed
+
+    # ---------------- roofline of the refinement scan (north_star's HBM-bound kernel) -----------------
+    # algorithmic bytes per launch: Q * (B*d*4 + d*4 + k*8)
+    ref_bytes = Q * (B * d * 4 + d * 4 + k * 8)
+    ref_ms = float(st_mean[3])
+    achieved = ref_bytes / (ref_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "refine_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("Q") == Q:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel="refine_scan_kernel<float,float,32,true>", achieved=round(achieved, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5))
+
+    # ---------------- recall@10 vs exact kNN of the synthetic set (reported, never assumed) ------------
+    recall = None
+    if rank == 0:
+        with torch.no_grad():
+            Xd = torch.from_numpy(X).to(dev)
+            xx = (Xd * Xd).sum(1)
+            gt = []
+            for s in range(0, Q, 256):
+                qq = q_dev[s:s + 256]
+                dd = xx[None, :] - 2.0 * (qq @ Xd.T)
+                gt.append(torch.topk(dd, k, dim=1, largest=False).indices)
+            gt = torch.cat(gt).cpu().numpy()
+            got = out_ids.cpu().numpy()
+            recall = float(np.mean([len(set(gt[i]) & set(got[i])) / k for i in range(Q)]))
+            del Xd
+
+    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) -----------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        O = graft.load_oracle()
+        o = O.Oracle(T, D, m, lam, d, refinement_limit=B)
+        a, r_, w_ = ctx.get_gfunctions()
+        o.set_gfunctions(a, r_, w_)
+        o.set_id_meta(n)
+        for td in range(TD):
+            o.set_index(td, **ctx.get_index(td))
+        o.set_store(X.astype(np.float64))
+        ns = min(args.cpu_sample, Q)
+        qs = Qh[:ns].astype(np.float64)
+        t1 = time.perf_counter()
+        cds = o.encode(qs[:8])  # warm
+        ref = o.search(qs[:8], k, codes=cds, threads=1)
+        t1 = time.perf_counter()
+        reps, done = 0, 0
+        while True:  # bounded: at least one pass, at most ~10 s
+            cds = o.encode(qs)
+            ref = o.search(qs, k, codes=cds, threads=1)
+            reps += 1
+            done += ns
+            if time.perf_counter() - t1 > 10.0 or reps >= 50:
+                break
+        cpu_s = time.perf_counter() - t1
+        same = bool(np.array_equal(ref["ids"], out_ids.cpu().numpy()[:ns]) and
+                    np.array_equal(ref["dist"], out_dist.cpu().numpy()[:ns]))
+        cpu = dict(value=round(done / cpu_s, 1), unit="queries/s", cores=1, kind="port",
+                   sample=f"{ns} queries x {reps} passes of the same batch (encode + Route + Refine on plaintext, "
+                          f"no AES/RocksDB), C++ oracle single thread; host has {os.cpu_count()} logical cores",
+                   matches_gpu=same)
+
+    if rank == 0:
+        out = {
+            "metric": "queries/sec @ recall@10, SIFT-1M d=128 B=256",
+            "value": round(qps, 1),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic N(0,1) fp32 vectors (SIFT-1M shape), exact-kNN ground truth of the synthetic set",
+            "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
+                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q,
+                       "parallelism": f"query-sharded x{world}, index replicated"},
+            "recall_at_10": recall,
+            "stages_ms": {"encode": round(float(st_mean[0]), 5), "route_select": round(float(st_mean[1]), 5),
+                          "stage_candidates": round(float(st_mean[2]), 5), "refine_topk": round(float(st_mean[3]), 5)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

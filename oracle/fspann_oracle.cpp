@@ -567,7 +567,6 @@ void search(Ctx& c, const double* q, const uint64_t* qCodes, int K, int probeOve
     if (!isValid(q, c.d)) return;  // :137-140
     bool retried = false;
     int probeOverride = probeOverrideIn;  // FSA:640-643 may have set a thread-local override
-    std::vector<uint8_t> touchedMark;
     while (true) {
         std::vector<Cand> cands;
         int rawSeen = 0;
@@ -602,7 +601,6 @@ void search(Ctx& c, const double* q, const uint64_t* qCodes, int K, int probeOve
         struct Scored { int32_t id; double dist; };
         std::vector<Scored> scored;
         scored.reserve(refineLimit);
-        if (touchedMark.empty()) touchedMark.assign((size_t)c.nIds, 0);
         for (int i = 0; i < refineLimit; i++) {  // :238-271
             int32_t id = candidateIds[i];
             // loadPointIfActive (PIS:717-724): deleted or missing -> null -> skipped
@@ -611,7 +609,7 @@ void search(Ctx& c, const double* q, const uint64_t* qCodes, int K, int probeOve
             const double* v = c.store.data() + (size_t)id * c.d;
             if (!isValid(v, c.d)) continue;  // :253-260
             scored.push_back({id, l2(q, v, c.d)});
-            if (!touchedMark[id]) { touchedMark[id] = 1; o.touched.push_back(id); }
+            o.touched.push_back(id);  // touchedThisSession.add(id) (:263); deduplicated on return
         }
         o.candDecrypted = (int)scored.size();  // :274
         if (scored.empty()) { o.ids.clear(); o.dist.clear(); o.returned = 0; return; }  // :293
@@ -632,6 +630,8 @@ void search(Ctx& c, const double* q, const uint64_t* qCodes, int K, int probeOve
             probeOverride = 10;
             continue;
         }
+        std::sort(o.touched.begin(), o.touched.end());  // Set semantics
+        o.touched.erase(std::unique(o.touched.begin(), o.touched.end()), o.touched.end());
         return;
     }
 }
