@@ -120,42 +120,55 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
 }
 
 struct RoutePlan {
-    int P, S, max_tuples, maxcand, ht_size, ht_shift, sort_cap_lds, use_lds_ht, nbins;
-    size_t lds_bytes;
+    int P, S, S_shift, max_tuples, maxcand, ht_size, ht_shift, sort_cap, nbins, need_cap, lds_mode;
+    size_t lds_bytes, arena_bytes;
     int grid;
     int threads;
     int64_t g_sort_stride;
 };
 
-int plan_route(fspann_ctx* c, int probe_override, int64_t nq, RoutePlan& pl) {
+int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, RoutePlan& pl) {
     pl.P = effective_probes(c, probe_override);
     pl.S = c->cfg.block_size;
+    pl.S_shift = ((pl.S & (pl.S - 1)) == 0) ? __builtin_ctz(pl.S) : -1;
     const int64_t mt = static_cast<int64_t>(c->TD) * pl.P * pl.S;
     if (mt > (1LL << kSeqBits)) return fail(FSPANN_E_RANGE, "T*D*probes*blockSize = %lld exceeds 2^%d tuple slots", (long long)mt, kSeqBits);
     pl.max_tuples = static_cast<int>(mt);
+    pl.need_cap = (mt >= c->hard_cap) ? 1 : 0;
     pl.maxcand = static_cast<int>(std::min<int64_t>(mt, static_cast<int64_t>(c->hard_cap) - 1 + pl.S));
-    pl.ht_size = std::max(64, next_pow2(static_cast<int64_t>(pl.maxcand) + pl.maxcand / 3 + 1));
+    // B1 inserts every tuple (also those behind a HARD_CAP cut): size for max_tuples, load factor <= 0.5
+    {   // load factor: <= 0.8 by default (2 workgroups per CU at BASELINE config #2); FSPANN_ROUTE_HT_X4=1 -> <= 0.5
+        const char* e = getenv("FSPANN_ROUTE_HT_X4");
+        const int64_t want = (e && e[0] == '1') ? static_cast<int64_t>(pl.max_tuples) * 2 : static_cast<int64_t>(pl.max_tuples) + pl.max_tuples / 4;
+        pl.ht_size = std::max(64, next_pow2(want));
+    }
     pl.ht_shift = 32 - __builtin_ctz(pl.ht_size);
     pl.nbins = c->bits + 1;
-    const int full_sort = next_pow2(std::max(pl.maxcand, 1));
-    const size_t fixed = static_cast<size_t>(pl.max_tuples) * 4 + static_cast<size_t>(pl.nbins) * 4 +
-                         static_cast<size_t>(c->TD) * pl.P * 8 + static_cast<size_t>(c->TD) * 4 + 64;
-    const size_t budget = static_cast<size_t>(c->lds_limit) - 2048;  // static __shared__ + margin
-    if (fixed + 1024 * 8 > budget)
-        return fail(FSPANN_E_RANGE, "route: %d tuple slots per query do not fit in LDS (%zu B needed)", pl.max_tuples, fixed);
-    pl.use_lds_ht = 1;
-    pl.sort_cap_lds = full_sort;
-    const size_t ht_bytes = static_cast<size_t>(pl.ht_size) * 8;
-    while (pl.sort_cap_lds > 1024 && fixed + ht_bytes + static_cast<size_t>(pl.sort_cap_lds) * 8 > budget) pl.sort_cap_lds >>= 1;
-    if (fixed + ht_bytes + static_cast<size_t>(pl.sort_cap_lds) * 8 > budget) {
-        pl.use_lds_ht = 0;
-        pl.sort_cap_lds = full_sort;
-        while (pl.sort_cap_lds > 1024 && fixed + static_cast<size_t>(pl.sort_cap_lds) * 8 > budget) pl.sort_cap_lds >>= 1;
+    {
+        const char* e = getenv("FSPANN_ROUTE_THREADS");
+        pl.threads = (e && atoi(e) == 1024) ? 1024 : 512;
     }
-    pl.lds_bytes = fixed + (pl.use_lds_ht ? ht_bytes : 0) + static_cast<size_t>(pl.sort_cap_lds) * 8;
-    pl.threads = 512;
-    pl.grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * 4));
-    pl.g_sort_stride = (pl.sort_cap_lds < full_sort) ? full_sort : 0;
+    const int full_sort = next_pow2(std::max(pl.maxcand, 1));
+    pl.sort_cap = std::min(full_sort, 1024);
+    const size_t TP = static_cast<size_t>(c->TD) * pl.P;
+    const size_t small = static_cast<size_t>(c->TD) * 8 + TP * 16 + 4096 + kDupListMax * 4 + TP * 4 + static_cast<size_t>(c->TD) * 8 + 64;
+    auto arena = [&](int sort_cap) {
+        return static_cast<size_t>(sort_cap) * 8 + static_cast<size_t>(pl.ht_size) * 4 + static_cast<size_t>(pl.max_tuples) * 4 +
+               ((static_cast<size_t>(pl.max_tuples) * 2 + 15) & ~size_t(15));
+    };
+    const size_t budget = static_cast<size_t>(c->lds_limit) - 1024;  // static __shared__ + margin
+    if (small + 8192 > budget) return fail(FSPANN_E_RANGE, "route: T*D*probes = %zu probe slots do not fit in LDS", TP);
+    pl.arena_bytes = (arena(pl.sort_cap) + 255) & ~size_t(255);
+    pl.lds_mode = (pl.arena_bytes + small <= budget) ? 1 : 0;
+    if (pl.lds_mode && limit > kRankSortMax) {
+        // long result lists: grow the LDS sort buffer while it fits (avoids the global sort fallback)
+        while (pl.sort_cap < full_sort && ((arena(pl.sort_cap * 2) + 255) & ~size_t(255)) + small <= budget) pl.sort_cap *= 2;
+        pl.arena_bytes = (arena(pl.sort_cap) + 255) & ~size_t(255);
+    }
+    pl.lds_bytes = pl.lds_mode ? pl.arena_bytes + small : small;
+    const int per_cu = std::max<int>(1, static_cast<int>(static_cast<size_t>(c->lds_limit) / (pl.lds_bytes + 512)));
+    pl.grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * std::min(per_cu, 4)));
+    pl.g_sort_stride = (pl.sort_cap < full_sort) ? full_sort : 0;
     return FSPANN_OK;
 }
 
@@ -244,6 +257,10 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
     c->P_total = c->TD * g.m;
     c->hard_cap = std::max(g.max_global_candidates, g.refinement_limit);  // PIS:612-615
     c->cap0 = table_size_for(std::min(c->hard_cap, 1 << 16));             // PIS:619
+    if (c->hard_cap > 700000) {
+        delete c;
+        return fail(FSPANN_E_ARG, "max(maxGlobalCandidates, refinementLimit) > 700000 exceeds the %d-bit bucket field", kBucketBits);
+    }
     if (c->cap0 < 64) {
         delete c;
         return fail(FSPANN_E_ARG, "max(maxGlobalCandidates, refinementLimit) < 33: HashMap order with a table shorter "
@@ -275,7 +292,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
     free_dev(c->d_store);
-    free_dev(c->ws_route.p); free_dev(c->ws_refine.p);
+    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p);
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -429,6 +446,7 @@ int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, c
     CHECK_CTX(c);
     if (n_ids <= 0 || n_ids >= (1LL << 31)) return fail(FSPANN_E_ARG, "n_ids out of range");
     c->h_java_hash.resize(static_cast<size_t>(n_ids));
+    c->decimal_ids = (java_hash == nullptr);
     if (java_hash) std::copy(java_hash, java_hash + n_ids, c->h_java_hash.begin());
     else for (int64_t i = 0; i < n_ids; i++) c->h_java_hash[i] = decimal_string_hash(i);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
@@ -545,35 +563,52 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     if (!ids_dev || !count_dev) return fail(FSPANN_E_NULL, "output buffer is null");
     if (limit <= 0) return fail(FSPANN_E_ARG, "limit must be > 0");
     RoutePlan pl;
-    int rc = plan_route(c, probe_override, nq, pl);
+    int rc = plan_route(c, probe_override, nq, limit, pl);
     if (rc) return rc;
     const int64_t need = std::min<int64_t>(limit, pl.maxcand);
     if (cap < need) return fail(FSPANN_E_RANGE, "cap %lld < min(limit, worst case) = %lld", (long long)cap, (long long)need);
-    size_t gbytes = 0;
-    const size_t ht_g = pl.use_lds_ht ? 0 : static_cast<size_t>(pl.grid) * 2 * pl.ht_size * 4;
+    const size_t ar_g = pl.lds_mode ? 0 : static_cast<size_t>(pl.grid) * pl.arena_bytes;
     const size_t so_g = static_cast<size_t>(pl.grid) * pl.g_sort_stride * 8;
-    gbytes = ht_g + so_g;
-    if (gbytes && (rc = ensure(c, c->ws_route, gbytes + 64))) return rc;
+    if (ar_g + so_g && (rc = ensure(c, c->ws_route, ar_g + so_g + 256))) return rc;
     RouteParams p{};
     p.codes = codes_dev; p.tables = c->d_tables; p.keys2 = c->d_keys2; p.rep = c->d_rep; p.id_off = c->d_off; p.ids = c->d_ids;
     p.java_hash = c->d_java_hash; p.deleted_bits = c->d_deleted_bits;
-    p.nq = nq; p.TD = c->TD; p.W = c->W; p.P = pl.P; p.S = pl.S;
-    p.hard_cap = c->hard_cap; p.cap0 = c->cap0; p.limit = limit; p.nbins = pl.nbins;
-    p.ht_size = pl.ht_size; p.ht_shift = pl.ht_shift; p.sort_cap_lds = pl.sort_cap_lds; p.max_tuples = pl.max_tuples;
-    p.use_lds_ht = pl.use_lds_ht;
+    p.nq = nq; p.TD = c->TD; p.W = c->W; p.P = pl.P; p.S = pl.S; p.S_shift = pl.S_shift;
+    p.hard_cap = c->hard_cap; p.cap0 = c->cap0; p.limit = limit; p.need_cap = pl.need_cap; p.nbins = pl.nbins;
+    p.ht_size = pl.ht_size; p.ht_shift = pl.ht_shift; p.sort_cap = pl.sort_cap; p.max_tuples = pl.max_tuples;
     p.g_sort = so_g ? static_cast<uint64_t*>(c->ws_route.p) : nullptr;
     p.g_sort_stride = pl.g_sort_stride;
-    p.g_ht = ht_g ? reinterpret_cast<uint32_t*>(static_cast<char*>(c->ws_route.p) + so_g) : nullptr;
+    p.g_scratch = ar_g ? static_cast<unsigned char*>(c->ws_route.p) + ((so_g + 255) & ~size_t(255)) : nullptr;
+    p.g_stride = static_cast<int64_t>(pl.arena_bytes);
+    p.dbg = c->dbg_route;
+    p.decimal_ids = c->decimal_ids ? 1 : 0;
     p.out_cap = cap; p.out_ids = ids_dev; p.out_score = score_dev; p.out_count = count_dev; p.out_kept = kept_dev; p.out_raw = raw_seen_dev;
-    if (pl.use_lds_ht) {
-        auto kern = route_kernel<true>;
-        FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds_bytes)));
-        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, c->stream, p);
-    } else {
-        auto kern = route_kernel<false>;
-        FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl.lds_bytes)));
-        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, c->stream, p);
+    // kernel 1: search + probe order, one lane group per (query, table)
+    const size_t TPn = static_cast<size_t>(c->TD) * pl.P;
+    const size_t probe_bytes = static_cast<size_t>(nq) * TPn * 16, np_bytes = static_cast<size_t>(nq) * c->TD * 4;
+    if ((rc = ensure(c, c->ws_probe, probe_bytes + np_bytes + 256))) return rc;
+    int4* probe_dev = static_cast<int4*>(c->ws_probe.p);
+    int32_t* nprobe_dev = reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_probe.p) + ((probe_bytes + 255) & ~size_t(255)));
+    {
+        int G = 64;
+        while (G > 2 && G / 2 >= 2 * pl.P - 1 && G / 2 >= 16) G >>= 1;  // >= 16 lanes per table: 3-4 search rounds
+        const int gpb = kProbeThreads / G;
+        const int64_t nitems = nq * c->TD;
+        const unsigned grid1 = static_cast<unsigned>((nitems + gpb - 1) / gpb);
+        const size_t lds1 = static_cast<size_t>(gpb) * (2 * pl.P - 1) * 12;
+        hipLaunchKernelGGL(route_probe_kernel, dim3(grid1), dim3(kProbeThreads), lds1, c->stream, p, probe_dev, nprobe_dev, G);
+        FSP_HIP(hipGetLastError());
     }
+#define FSP_LAUNCH_SEL(LDS, THR)                                                                                         \
+    do {                                                                                                                 \
+        auto kern = route_select_kernel<LDS, THR>;                                                                       \
+        FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                    static_cast<int>(pl.lds_bytes)));                                                    \
+        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(THR), pl.lds_bytes, c->stream, p, probe_dev, nprobe_dev);           \
+    } while (0)
+    if (pl.lds_mode) { if (pl.threads == 1024) FSP_LAUNCH_SEL(true, 1024); else FSP_LAUNCH_SEL(true, 512); }
+    else { if (pl.threads == 1024) FSP_LAUNCH_SEL(false, 1024); else FSP_LAUNCH_SEL(false, 512); }
+#undef FSP_LAUNCH_SEL
     FSP_HIP(hipGetLastError());
     return FSPANN_OK;
 }
@@ -707,6 +742,13 @@ int fspann_store_gather_dev(fspann_ctx* c, int64_t nq, const int32_t* sel_ids_de
                            sel_ids_dev, sel_count_dev, B, nq, static_cast<double*>(cand_dev), vec_ok);
     }
     FSP_HIP(hipGetLastError());
+    return FSPANN_OK;
+}
+
+// debug: per-block phase stamps of the route kernel (dev pointer to [grid][8] int64, or NULL)
+int fspann_debug_route_stamps(fspann_ctx* c, void* dev_ptr) {
+    if (!c) return FSPANN_E_NULL;
+    c->dbg_route = static_cast<long long*>(dev_ptr);
     return FSPANN_OK;
 }
 

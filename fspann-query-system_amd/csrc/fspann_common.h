@@ -76,6 +76,7 @@ struct fspann_ctx {
     int lds_limit = 160 * 1024;
     bool frozen = false;
     bool have_g = false;
+    long long* dbg_route = nullptr;  // debug stamps (fspann_debug_route_stamps)
 
     // GFunctions: alphaT[dim][P_total] fp64 (transposed for coalescing), r/omega[P_total]
     double* d_alphaT = nullptr;
@@ -102,6 +103,7 @@ struct fspann_ctx {
     int32_t* d_java_hash = nullptr;
     uint32_t* d_deleted_bits = nullptr;  // nullptr => nothing deleted
     std::vector<int32_t> h_java_hash;
+    bool decimal_ids = false;  // ids are Long.toString(handle): String.hashCode computed in-kernel
 
     // plaintext store (test / bench harness)
     void* d_store = nullptr;
@@ -110,6 +112,7 @@ struct fspann_ctx {
 
     // scratch arenas (grown on demand, reused across calls)
     fspann::DevBuf ws_route;   // global hash/sort fallback for the route kernel
+    fspann::DevBuf ws_probe;   // probe lists handed from route_probe_kernel to route_select_kernel
     fspann::DevBuf ws_refine;  // per-chunk partial top-k
     fspann::DevBuf ws_io[8];   // staging for the host-pointer entry points
 };

@@ -10,46 +10,53 @@
 // HashMap<String,Long> (PIS:726-753) -> the map's entries, in iteration order,
 // stable-sorted by score (PIS:690-696) -> QSI keeps the first B (QSI:208-214).
 //
-// How it is done here (see DESIGN.md "Route kernel" for the derivations):
-//   phase A  one lane per table: key, literal binary search, literal 2-entry heap.
-//   phase A2 all lanes: stage the ids of every probed partition into LDS, tuple
-//            slot seq = (td*P + step)*S + pos (this IS the reference's insertion
-//            order); deleted ids become -1.
-//   phase B  tables in order, one barrier per table: open-addressed LDS hash keyed
-//            by id holding (min score, first seq).  An id occurs at most once per
-//            table, so inside a phase no two lanes touch the same entry; entry
-//            creation is the only race and is resolved by atomicCAS on the key.
-//            HARD_CAP (PIS:612-615,624,628,657-659) is honoured at probe-step
-//            granularity exactly like the reference's loop guards.
-//   phase C  Java order key = (score, bucket(id) at the final HashMap capacity,
-//            first seq); histogram over score -> cut score s*; entries with
-//            score <= s* are compacted and bitonic-sorted in LDS; the first
-//            `limit` are written out.
+// How it is done here (derivations in DESIGN.md "Route kernel"); A is its own kernel
+// (route_probe_kernel, one wave per (query, table) -> full occupancy for the dependent
+// L2 rounds), A2..C are route_select_kernel (one workgroup per query, all state in LDS):
+//   A   one lane GROUP (G = 64 / tables-per-wave lanes) per table: G-ary search for the run [a,b] of partitions whose
+//       key range holds the query key, then the reference's binary search is
+//       replayed arithmetically against (a,b) — same `mid` sequence, no dependent
+//       loads; Hamming distances of the 2P-1 reachable partitions are fetched in
+//       one round and the 2-entry PriorityQueue is replayed from LDS.
+//   A2  all lanes: ids of every probed partition -> LDS tuple slots,
+//       seq = (td*P + step)*S + pos (= the reference's insertion order).
+//   B1  (fused with A2) all tuples in parallel: open-addressed LDS hash, 4-byte
+//       entries holding the FIRST seq of an id (atomicMin); identity is checked
+//       through tup[seq]; double hashing.  Every atomicMin that meets an occupied
+//       entry exposes exactly one repeated occurrence (the larger seq): those go to
+//       a small list; the score histogram of first occurrences is kept up to date.
+//   B2  HARD_CAP (PIS:612-615,624,628,657-659; rare): distinct-count per probe step
+//       -> first step at which size >= cap; later steps never ran.
+//   B3  repeated occurrences: min score and the number of strict improvements in
+//       table order (= rawSeen - created, PIS:744-750), all repeats in parallel.
+//   C   Java order key (score | HashMap bucket at the final capacity | first seq):
+//       radix-select on score, then on the bucket's top bits, down to <= ~limit
+//       candidates; all-pairs rank sort (no barriers) writes the first `limit`.
 #pragma once
 #include "fspann_common.h"
 
 namespace fspann {
 
 struct RouteParams {
-    const uint64_t* codes;       // [nq][TD][W]
-    const RouteTable* tables;    // [TD]
-    const int64_t* keys2;        // [parts][2]
-    const uint64_t* rep;         // [parts][W]
-    const int32_t* id_off;       // per table nparts+1
+    const uint64_t* codes;         // [nq][TD][W]
+    const RouteTable* tables;      // [TD]
+    const int64_t* keys2;          // [parts][2] {minKey,maxKey}
+    const uint64_t* rep;           // [parts][W]
+    const int32_t* id_off;         // per table nparts+1
     const int32_t* ids;
-    const int32_t* java_hash;    // [n_ids]
+    const int32_t* java_hash;      // [n_ids]
     const uint32_t* deleted_bits;  // may be null
     int64_t nq;
-    int TD, W, P, S;
+    int TD, W, P, S, S_shift;      // S_shift = log2(S) or -1
     int hard_cap, cap0, limit;
-    int nbins;                   // bits + 1 score bins
-    int ht_size;                 // power of two
-    int ht_shift;                // 32 - log2(ht_size)
-    int sort_cap_lds;            // LDS sort entries (power of two), 0 => always global
-    int max_tuples;              // TD*P*S
-    int use_lds_ht;
-    uint32_t* g_ht;              // global fallback: per block 2*ht_size u32
-    uint64_t* g_sort;            // global fallback: per block g_sort_stride u64
+    int need_cap;                  // 1 if TD*P*S >= hard_cap (the cap can trigger)
+    int nbins;                     // bits + 1 score bins (<= 1024)
+    int ht_size, ht_shift;         // power of two; shift = 32 - log2
+    int sort_cap;                  // entries of the per-block sort buffer (LDS or global)
+    int max_tuples;                // TD*P*S
+    unsigned char* g_scratch;      // global fallback arena (per block g_stride bytes) when !kLds
+    int64_t g_stride;
+    uint64_t* g_sort;              // global sort fallback (per block g_sort_stride u64), may be null
     int64_t g_sort_stride;
     int64_t out_cap;
     int32_t* out_ids;
@@ -57,6 +64,8 @@ struct RouteParams {
     int32_t* out_count;
     int32_t* out_kept;
     int32_t* out_raw;
+    int decimal_ids;               // 1: ids are Long.toString(handle) -> hash computed arithmetically
+    long long* dbg;                // optional [grid][16] wall_clock64 stamps of each block's first query
 };
 
 __device__ __forceinline__ int ham_words(const uint64_t* a, const uint64_t* b, int W) {
@@ -65,8 +74,8 @@ __device__ __forceinline__ int ham_words(const uint64_t* a, const uint64_t* b, i
     return c;
 }
 
-// threshold evolution of java.util.HashMap.resize(): returns the table length after
-// n insertions into new HashMap<>(cap0-sized) (no treeification, cap0 >= 64).
+// java.util.HashMap.resize() threshold evolution: table length after n insertions into
+// new HashMap<>(cap0-sized) (no treeification, cap0 >= 64).
 __device__ __forceinline__ int java_final_cap(int cap0, int n) {
     int cap = cap0;
     int thr = static_cast<int>(static_cast<float>(cap) * 0.75f);
@@ -98,242 +107,572 @@ __device__ __forceinline__ void bitonic_sort_u64(PtrT sb, int n2, int tid, int n
     }
 }
 
-template <bool kLdsHT>
-__global__ __launch_bounds__(512) void route_kernel(RouteParams prm) {
+constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;
+constexpr uint16_t kFirstFlag = 0x8000u;  // tscore: first occurrence of its id (score in the low 14 bits)
+constexpr int kRankSortMax = 1024;
+
+// String.hashCode(Long.toString(v)), v >= 0: h = sum (48 + digit_i) * 31^i over digits from the LSB.
+__device__ __forceinline__ uint32_t decimal_string_hash_dev(uint32_t v) {
+    uint32_t h = 0, pw = 1;
+    do {
+        const uint32_t q = v / 10u, dgt = v - q * 10u;
+        h += (48u + dgt) * pw;
+        pw *= 31u;
+        v = q;
+    } while (v);
+    return h;
+}
+
+constexpr int kProbeThreads = 256;
+constexpr int kDupListMax = 512;
+constexpr uint16_t kLiveFlag = 0x4000u;   // tscore: tuple slot holds a live (non-deleted) id
+
+// First index b in [0, nb) with prefix(b) >= need, computed by ONE wave (nb <= 1024).
+// Returns b (nb - 1 if the total is smaller) and the count strictly before b through *before.
+__device__ __forceinline__ int wave_find_cut(const int32_t* bins, int nb, int need, int lane, int* before) {
+    const int per = (nb + 63) >> 6;
+    const int b0 = lane * per;
+    int sum = 0;
+    for (int i = 0; i < per; i++) sum += (b0 + i < nb) ? bins[b0 + i] : 0;
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    const int excl = incl - sum;
+    const bool mine = (incl >= need) && (excl < need);
+    const unsigned long long bm = __ballot(mine);
+    int res_b = nb - 1, res_before = 0;
+    if (bm == 0) {  // total < need: everything before the last bin
+        res_before = __shfl(incl, 63) - bins[nb - 1];
+    } else {
+        const int src = __ffsll(static_cast<long long>(bm)) - 1;
+        int cum = excl, bb = nb - 1;
+        if (lane == src) {
+            for (int i = 0; i < per && b0 + i < nb; i++) {
+                if (cum + bins[b0 + i] >= need) { bb = b0 + i; break; }
+                cum += bins[b0 + i];
+            }
+        }
+        res_b = __shfl(bb, src);
+        res_before = __shfl(cum, src);
+    }
+    *before = res_before;
+    return res_b;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1: search + probe order.  One lane group (G lanes) per (query, table).
+// probe_out[(q*TD + td)*P + step] = {partition, Hamming, id_off b0, size}; nprobe_out[q*TD + td].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams prm, int4* __restrict__ probe_out,
+                                                                   int32_t* __restrict__ nprobe_out, int G) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int nthreads = blockDim.x;
-    const int TD = prm.TD, W = prm.W, P = prm.P, S = prm.S;
+    const int lane = tid & 63;
+    const int TD = prm.TD, W = prm.W, P = prm.P;
+    const int nd = 2 * P - 1;
+    const int gpb = kProbeThreads / G;                 // groups per block
+    const int grp_in_wave = lane / G, gl = lane - grp_in_wave * G;
+    const int grp_in_block = tid / G;
+    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp_in_wave * G));
+    int32_t* w3 = reinterpret_cast<int32_t*>(smem) + static_cast<size_t>(grp_in_block) * nd * 3;  // [nd][3]
 
-    // ---- carve LDS -----------------------------------------------------------
-    uint64_t* lds_sort = reinterpret_cast<uint64_t*>(smem);
-    size_t o = static_cast<size_t>(prm.sort_cap_lds) * 8;
-    uint32_t* lds_htk = reinterpret_cast<uint32_t*>(smem + o);
-    if (kLdsHT) o += static_cast<size_t>(prm.ht_size) * 8;
-    uint32_t* lds_htv = lds_htk + prm.ht_size;
-    int32_t* tup = reinterpret_cast<int32_t*>(smem + o);
-    o += static_cast<size_t>(prm.max_tuples) * 4;
-    int32_t* hist = reinterpret_cast<int32_t*>(smem + o);
-    o += static_cast<size_t>(prm.nbins) * 4;
-    int32_t* probe_part = reinterpret_cast<int32_t*>(smem + o);
-    o += static_cast<size_t>(TD) * P * 4;
-    int32_t* probe_dist = reinterpret_cast<int32_t*>(smem + o);
-    o += static_cast<size_t>(TD) * P * 4;
-    int32_t* nprobe = reinterpret_cast<int32_t*>(smem + o);
+    const int64_t item = static_cast<int64_t>(blockIdx.x) * gpb + grp_in_block;  // (q, td) flattened
+    const int64_t nitems = prm.nq * TD;
+    const bool in_range = item < nitems;
+    const int64_t qi = in_range ? item / TD : 0;
+    const int td = in_range ? static_cast<int>(item - qi * TD) : 0;
+    const RouteTable tb = prm.tables[td];
+    const bool act = in_range && tb.nparts > 0;
+    const uint64_t* qc = prm.codes + (qi * TD + td) * W;
+    // GreedyPartitioner.computeKey: code bit i -> key bit 62-i (i < 63)
+    const int64_t qKey = act ? static_cast<int64_t>(__brevll(qc[0]) >> 1) : 0;
+    const int64_t* k2 = prm.keys2 + tb.part_base * 2;
+    // a = first partition with maxKey >= qKey ; e = first partition with minKey > qKey.
+    // G-ary search, both at once.  Invariant: answer in [lo, hi], hi == nparts or pred(hi) true.
+    int loA = 0, hiA = act ? tb.nparts : 0, loE = 0, hiE = hiA;
+    while (__any((hiA > loA) || (hiE > loE))) {
+        const int stA = (hiA - loA + G - 1) / G, stE = (hiE - loE + G - 1) / G;
+        const int sA = loA + gl * stA, sE = loE + gl * stE;  // my segment starts
+        bool pA = false, pE = false;
+        if (hiA > loA && sA < hiA) pA = k2[2 * static_cast<int64_t>(min(sA + stA, hiA) - 1) + 1] >= qKey;
+        if (hiE > loE && sE < hiE) pE = k2[2 * static_cast<int64_t>(min(sE + stE, hiE) - 1)] > qKey;
+        const unsigned long long bA = __ballot(pA) & gmask, bE = __ballot(pE) & gmask;
+        if (hiA > loA) {
+            if (bA == 0) loA = hiA;
+            else {
+                const int f = (__ffsll(static_cast<long long>(bA)) - 1) - grp_in_wave * G;
+                const int nlo = loA + f * stA;
+                hiA = min(nlo + stA, hiA) - 1;
+                loA = nlo;
+            }
+        }
+        if (hiE > loE) {
+            if (bE == 0) loE = hiE;
+            else {
+                const int f = (__ffsll(static_cast<long long>(bE)) - 1) - grp_in_wave * G;
+                const int nlo = loE + f * stE;
+                hiE = min(nlo + stE, hiE) - 1;
+                loE = nlo;
+            }
+        }
+    }
+    int center = 0;
+    if (act) {
+        const int a = loA, b = loE - 1;
+        if (a <= b) {
+            // replay findNearestPartition's loop: mid > b <=> qKey < minKey[mid]; mid < a <=> qKey > maxKey[mid]
+            int lo = 0, hi = tb.nparts - 1;
+            center = a;
+            while (lo <= hi) {
+                const int mid = static_cast<int>((static_cast<unsigned>(lo) + static_cast<unsigned>(hi)) >> 1);
+                if (mid > b) hi = mid - 1;
+                else if (mid < a) lo = mid + 1;
+                else { center = mid; break; }
+            }
+        } else {
+            const int lo = a;  // the loop ends with lo = first partition with minKey > qKey
+            if (lo <= 0) center = 0;
+            else if (lo >= tb.nparts) center = tb.nparts - 1;
+            else {
+                const int64_t lmax = k2[2 * static_cast<int64_t>(lo - 1) + 1];
+                const int64_t rmin = k2[2 * static_cast<int64_t>(lo)];
+                const int64_t dl = qKey - lmax, dr = rmin - qKey;  // distanceToRange
+                center = (dl <= dr) ? (lo - 1) : lo;
+            }
+        }
+        // one round: Hamming(q, rep) + id range of every partition reachable with P probes
+        const uint64_t* repb = prm.rep + tb.part_base * W;
+        for (int l = gl; l < nd; l += G) {
+            const int part = center - (P - 1) + l;
+            int dd = 0, b0 = 0, sz = 0;
+            if (part >= 0 && part < tb.nparts) {
+                dd = ham_words(qc, repb + static_cast<int64_t>(part) * W, W);
+                const int32_t* off = prm.id_off + tb.off_base + part;
+                b0 = off[0];
+                sz = off[1] - b0;
+            }
+            w3[l * 3 + 0] = dd; w3[l * 3 + 1] = b0; w3[l * 3 + 2] = sz;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+        // java.util.PriorityQueue with <= 2 live entries: offer() makes the newcomer the root only
+        // if STRICTLY smaller (siftUp); poll() promotes the survivor (siftDown on one element).
+        int4* po = probe_out + item * P;
+        int np = 0;
+        int h_idx0 = center, h_d0 = w3[(P - 1) * 3];
+        int h_idx1 = 0, h_d1 = 0, hn = 1;
+        int vlo = center, vhi = center;
+        while (hn > 0 && np < P) {
+            const int cur = h_idx0, curd = h_d0;
+            hn--;
+            if (hn == 1) { h_idx0 = h_idx1; h_d0 = h_d1; }
+            if (gl == 0) {
+                const int ci = cur - center + (P - 1);
+                po[np] = make_int4(cur, curd, w3[ci * 3 + 1], w3[ci * 3 + 2]);
+            }
+            np++;
+            const int left = cur - 1;
+            if (left >= 0 && left < vlo) {
+                vlo = left;
+                const int li = left - center + (P - 1);
+                const int dd = (li >= 0 && li < nd) ? w3[li * 3] : 0;  // out of reach: never polled
+                if (hn == 0) { h_idx0 = left; h_d0 = dd; }
+                else if (dd < h_d0) { h_idx1 = h_idx0; h_d1 = h_d0; h_idx0 = left; h_d0 = dd; }
+                else { h_idx1 = left; h_d1 = dd; }
+                hn++;
+            }
+            const int right = cur + 1;
+            if (right < tb.nparts && right > vhi) {
+                vhi = right;
+                const int ri = right - center + (P - 1);
+                const int dd = (ri >= 0 && ri < nd) ? w3[ri * 3] : 0;
+                if (hn == 0) { h_idx0 = right; h_d0 = dd; }
+                else if (dd < h_d0) { h_idx1 = h_idx0; h_d1 = h_d0; h_idx0 = right; h_d0 = dd; }
+                else { h_idx1 = right; h_d1 = dd; }
+                hn++;
+            }
+        }
+        if (gl == 0) nprobe_out[item] = np;
+    } else if (in_range && gl == 0) {
+        nprobe_out[item] = 0;
+    }
+}
 
-    __shared__ int s_phase[3];
-    __shared__ int s_raw;
-    __shared__ int s_fill;
-    __shared__ int s_star;
-    __shared__ int s_sel;
+// ------------------------------------------------------------------------------------------
+// Kernel 2: stage ids, dedupe, Java order, select.  One workgroup per query.
+// ------------------------------------------------------------------------------------------
+template <bool kLds, int kThreads>
+__global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm, const int4* __restrict__ probe_in,
+                                                                const int32_t* __restrict__ nprobe_in) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    constexpr int nthreads = kThreads;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int TD = prm.TD, P = prm.P, S = prm.S;
+    const int TP = TD * P;
 
-    uint32_t* htk = kLdsHT ? lds_htk : prm.g_ht + static_cast<size_t>(blockIdx.x) * 2 * prm.ht_size;
-    uint32_t* htv = kLdsHT ? lds_htv : htk + prm.ht_size;
+    // ---- carve the per-query arrays (LDS, or the global arena when they do not fit) -----
+    unsigned char* arena = kLds ? smem : prm.g_scratch + static_cast<int64_t>(blockIdx.x) * prm.g_stride;
+    size_t o = 0;
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(arena + o);  o += static_cast<size_t>(prm.sort_cap) * 8;
+    uint32_t* ht = reinterpret_cast<uint32_t*>(arena + o);       o += static_cast<size_t>(prm.ht_size) * 4;
+    int32_t* tup = reinterpret_cast<int32_t*>(arena + o);        o += static_cast<size_t>(prm.max_tuples) * 4;
+    uint16_t* tscore = reinterpret_cast<uint16_t*>(arena + o);   o += (static_cast<size_t>(prm.max_tuples) * 2 + 15) & ~size_t(15);
+    // small arrays always live in LDS
+    unsigned char* sm = kLds ? smem + o : smem;
+    size_t so = 0;
+    int64_t* ids_base = reinterpret_cast<int64_t*>(sm + so);     so += static_cast<size_t>(TD) * 8;
+    int4* probe = reinterpret_cast<int4*>(sm + so);              so += static_cast<size_t>(TP) * 16;
+    int32_t* bins = reinterpret_cast<int32_t*>(sm + so);         so += 1024 * 4;
+    int32_t* duplist = reinterpret_cast<int32_t*>(sm + so);      so += kDupListMax * 4;
+    int32_t* stepcnt = reinterpret_cast<int32_t*>(sm + so);      so += static_cast<size_t>(TP) * 4;
+    int32_t* nprobe = reinterpret_cast<int32_t*>(sm + so);       so += static_cast<size_t>(TD) * 4;
+    int32_t* dupcnt = reinterpret_cast<int32_t*>(sm + so);       // [TD]
+
+    __shared__ int s_n, s_raw, s_fill, s_cut, s_star, s_need, s_b1, s_lvl1, s_ndup;
+
     const uint32_t ht_mask = static_cast<uint32_t>(prm.ht_size - 1);
 
+    for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
+
+#define FSP_STAMP(i) do { if (prm.dbg && tid == 0 && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define FSP_TS(j) ((prm.S_shift >= 0) ? ((j) >> prm.S_shift) : ((j) / S))
+    const bool wave_uniform_ts = (prm.S_shift >= 6);  // 64 consecutive tuple slots share one probe step
+
+    // probe the hash for `id`; returns the slot that holds it (must exist)
+    auto find_slot = [&](int32_t id) -> uint32_t {
+        uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
+        const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> prm.ht_shift) | 1u;
+        while (true) {
+            const uint32_t cur = ht[slot];
+            if (cur != kHtEmpty && tup[cur] == id) return slot;
+            slot = (slot + stp) & ht_mask;
+        }
+    };
+
     for (int64_t qi = blockIdx.x; qi < prm.nq; qi += gridDim.x) {
-        // ---- reset ------------------------------------------------------------
-        for (int i = tid; i < prm.ht_size; i += nthreads) htk[i] = kEmptyKey;
-        for (int i = tid; i < prm.nbins; i += nthreads) hist[i] = 0;
-        if (tid < 3) s_phase[tid] = 0;
-        if (tid == 0) { s_raw = 0; s_fill = 0; }
+        FSP_STAMP(0);
+        // ---- reset (16-byte stores) + probe list of this query -------------------------------
+        {
+            uint4* h4 = reinterpret_cast<uint4*>(ht);
+            const uint4 e4 = make_uint4(kHtEmpty, kHtEmpty, kHtEmpty, kHtEmpty);
+            for (int i = tid; i < prm.ht_size / 4; i += nthreads) h4[i] = e4;
+            uint4* t4 = reinterpret_cast<uint4*>(tscore);
+            const int nt4 = (prm.max_tuples * 2 + 15) / 16;
+            for (int i = tid; i < nt4; i += nthreads) t4[i] = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;
+            for (int i = tid; i < TP; i += nthreads) { stepcnt[i] = 0; probe[i] = probe_in[qi * TP + i]; }
+            for (int i = tid; i < TD; i += nthreads) { dupcnt[i] = 0; nprobe[i] = nprobe_in[qi * TD + i]; }
+            if (tid == 0) { s_n = 0; s_raw = 0; s_fill = 0; s_cut = 0x7FFFFFFF; s_ndup = 0; s_lvl1 = 0; }
+        }
+        __syncthreads();
+        FSP_STAMP(1);
 
-        // ---- phase A: per-table search + probe order ---------------------------
-        for (int td = tid; td < TD; td += nthreads) {
-            const RouteTable tb = prm.tables[td];
-            const uint64_t* qc = prm.codes + (qi * TD + td) * W;
-            int np = 0;
-            if (tb.nparts > 0) {
-                // GreedyPartitioner.computeKey: bit i of the code -> key bit 62-i, i < 63
-                const int64_t qKey = static_cast<int64_t>(__brevll(qc[0]) >> 1);
-                const int64_t* k2 = prm.keys2 + tb.part_base * 2;
-                int lo = 0, hi = tb.nparts - 1, center = -1;
-                while (lo <= hi) {
-                    const int mid = static_cast<int>((static_cast<unsigned>(lo) + static_cast<unsigned>(hi)) >> 1);
-                    const longlong2 mm = *reinterpret_cast<const longlong2*>(k2 + 2 * static_cast<int64_t>(mid));
-                    if (qKey < mm.x) hi = mid - 1;
-                    else if (qKey > mm.y) lo = mid + 1;
-                    else { center = mid; break; }
-                }
-                if (center < 0) {
-                    if (lo <= 0) center = 0;
-                    else if (lo >= tb.nparts) center = tb.nparts - 1;
-                    else {
-                        const longlong2 L = *reinterpret_cast<const longlong2*>(k2 + 2 * static_cast<int64_t>(lo - 1));
-                        const longlong2 R = *reinterpret_cast<const longlong2*>(k2 + 2 * static_cast<int64_t>(lo));
-                        const int64_t dl = (qKey < L.x) ? (L.x - qKey) : ((qKey > L.y) ? (qKey - L.y) : 0);
-                        const int64_t dr = (qKey < R.x) ? (R.x - qKey) : ((qKey > R.y) ? (qKey - R.y) : 0);
-                        center = (dl <= dr) ? (lo - 1) : lo;
-                    }
-                }
-                // java.util.PriorityQueue with <= 2 live entries (left / right frontier).
-                // offer(): the newcomer becomes the root only if STRICTLY smaller (siftUp);
-                // poll(): the survivor becomes the root (siftDown on one element).
-                const uint64_t* repb = prm.rep + tb.part_base * W;
-                int h_idx0 = center, h_d0 = ham_words(qc, repb + static_cast<int64_t>(center) * W, W);
-                int h_idx1 = 0, h_d1 = 0, hn = 1;
-                int vlo = center, vhi = center;
-                while (hn > 0 && np < P) {
-                    const int cur = h_idx0, curd = h_d0;
-                    hn--;
-                    if (hn == 1) { h_idx0 = h_idx1; h_d0 = h_d1; }
-                    probe_part[td * P + np] = cur;
-                    probe_dist[td * P + np] = curd;
-                    np++;
-                    const int left = cur - 1;
-                    if (left >= 0 && left < vlo) {
-                        vlo = left;
-                        const int dd = ham_words(qc, repb + static_cast<int64_t>(left) * W, W);
-                        if (hn == 0) { h_idx0 = left; h_d0 = dd; }
-                        else if (dd < h_d0) { h_idx1 = h_idx0; h_d1 = h_d0; h_idx0 = left; h_d0 = dd; }
-                        else { h_idx1 = left; h_d1 = dd; }
-                        hn++;
-                    }
-                    const int right = cur + 1;
-                    if (right < tb.nparts && right > vhi) {
-                        vhi = right;
-                        const int dd = ham_words(qc, repb + static_cast<int64_t>(right) * W, W);
-                        if (hn == 0) { h_idx0 = right; h_d0 = dd; }
-                        else if (dd < h_d0) { h_idx1 = h_idx0; h_d1 = h_d0; h_idx0 = right; h_d0 = dd; }
-                        else { h_idx1 = right; h_d1 = dd; }
-                        hn++;
-                    }
+        // ---- A2 + B1 fused: stage ids, build the hash: ht[slot] = min seq of the id owning the slot ----
+        for (int j0 = tid; j0 < prm.max_tuples; j0 += nthreads * 8) {
+            int32_t idv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u * nthreads;
+                idv[u] = -1;
+                if (j < prm.max_tuples) {
+                    const int ts = FSP_TS(j), pos = j - ts * S;
+                    const int td = ts / P, step = ts - td * P;
+                    const int4 pr = probe[ts];
+                    if (step < nprobe[td] && pos < pr.w) idv[u] = prm.ids[ids_base[td] + pr.z + pos];
                 }
             }
-            nprobe[td] = np;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u * nthreads;
+                if (j >= prm.max_tuples) continue;
+                int32_t id = idv[u];
+                if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1;
+                const int ts = FSP_TS(j);
+                const int sc = probe[ts].y;
+                tup[j] = id;  // written before the CAS below publishes j (same wave: LDS ops stay in order)
+                if (id >= 0) tscore[j] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
+                // histogram of (presumed) first occurrences + live tuples per probe step
+                if (wave_uniform_ts) {
+                    const int c1 = __popcll(__ballot(id >= 0));
+                    if (lane == 0 && c1) { atomicAdd(&bins[sc], c1); atomicAdd(&stepcnt[ts], c1); }
+                } else if (id >= 0) {
+                    atomicAdd(&bins[sc], 1);
+                    atomicAdd(&stepcnt[ts], 1);
+                }
+                if (id < 0) continue;
+                uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
+                const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> prm.ht_shift) | 1u;
+                while (true) {
+                    uint32_t cur = ht[slot];
+                    if (cur == kHtEmpty) {
+                        cur = atomicCAS(&ht[slot], kHtEmpty, static_cast<uint32_t>(j));
+                        if (cur == kHtEmpty) break;  // created
+                    }
+                    if (tup[cur] == id) {            // same id (whichever occurrence currently sits there)
+                        const uint32_t old = atomicMin(&ht[slot], static_cast<uint32_t>(j));
+                        const uint32_t loser = max(old, static_cast<uint32_t>(j));  // exactly one repeat per meeting
+                        const int pos = atomicAdd(&s_ndup, 1);
+                        if (pos < kDupListMax) duplist[pos] = static_cast<int32_t>(loser);
+                        break;
+                    }
+                    slot = (slot + stp) & ht_mask;
+                }
+            }
+        }
+        __syncthreads();
+        FSP_STAMP(2);
+
+        const int ndup = s_ndup;
+        // ---- repeats: drop them from "first" bookkeeping -----------------------------------------
+        // (list path when they fit; otherwise recompute the flags from the hash slots)
+        if (ndup <= kDupListMax) {
+            for (int l = tid; l < ndup; l += nthreads) {
+                const int j = duplist[l];
+                const uint16_t v = tscore[j];
+                tscore[j] = v & ~kFirstFlag;
+                const int ts = FSP_TS(j);
+                atomicSub(&bins[v & 0x3FFF], 1);
+                atomicSub(&stepcnt[ts], 1);
+                atomicAdd(&dupcnt[ts / P], 1);
+            }
+        } else {
+            for (int j = tid; j < prm.max_tuples; j += nthreads) tscore[j] &= ~kFirstFlag;
+            for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;
+            for (int i = tid; i < TP; i += nthreads) stepcnt[i] = 0;
+            __syncthreads();
+            for (int sl = tid; sl < prm.ht_size; sl += nthreads) {
+                const uint32_t j = ht[sl];
+                if (j == kHtEmpty) continue;
+                tscore[j] |= kFirstFlag;
+                atomicAdd(&bins[tscore[j] & 0x3FFF], 1);
+                atomicAdd(&stepcnt[FSP_TS(static_cast<int>(j))], 1);
+            }
+            __syncthreads();
+            for (int j = tid; j < prm.max_tuples; j += nthreads) {
+                const uint16_t v = tscore[j];
+                if ((v & kLiveFlag) && !(v & kFirstFlag)) atomicAdd(&dupcnt[FSP_TS(j) / P], 1);
+            }
         }
         __syncthreads();
 
-        // ---- phase A2: stage ids of all probed partitions ----------------------
-        for (int j = tid; j < prm.max_tuples; j += nthreads) {
-            const int ts = j / S, pos = j - ts * S;
-            const int td = ts / P, step = ts - td * P;
-            int32_t id = -1;
-            if (step < nprobe[td]) {
-                const RouteTable tb = prm.tables[td];
-                const int part = probe_part[ts];
-                const int32_t* off = prm.id_off + tb.off_base + part;
-                const int b0 = off[0], b1 = off[1];
-                if (pos < b1 - b0) {
-                    id = prm.ids[tb.ids_base + b0 + pos];
-                    if (prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1;
+        // ---- B2: HARD_CAP — first probe step at which bestScore.size() reaches the cap ----------------
+        int cut = 0x7FFFFFFF;
+        if (prm.need_cap) {
+            if (tid == 0) {
+                int cum = 0, c = 0x7FFFFFFF;
+                for (int g = 0; g < TP; g++) {
+                    cum += stepcnt[g];
+                    if (cum >= prm.hard_cap) { c = g; break; }  // steps after g never run (PIS:657-659)
                 }
+                s_cut = c;
             }
-            tup[j] = id;
-        }
-        __syncthreads();
-
-        // ---- phase B: ordered insertion -----------------------------------------
-        int size = 0;   // bestScore.size(), identical in every lane
-        int phase = 0;  // rotation index into s_phase
-        bool stop = false;
-        for (int td = 0; td < TD && !stop; td++) {
-            const int np = nprobe[td];
-            if (np == 0) continue;
-            if (size >= prm.hard_cap) break;  // PIS:624,628
-            const bool whole = (size + (np - 1) * S < prm.hard_cap);
-            const int nsub = whole ? 1 : np;
-            for (int sub = 0; sub < nsub; sub++) {
-                if (size >= prm.hard_cap) { stop = true; break; }  // PIS:657-659
-                const int j0 = (td * P + (whole ? 0 : sub)) * S;
-                const int j1 = whole ? (td * P + np) * S : j0 + S;
-                int created = 0, touched = 0;
-                for (int j = j0 + tid; j < j1; j += nthreads) {
-                    const int32_t id = tup[j];
-                    if (id < 0) continue;
-                    const uint32_t score = static_cast<uint32_t>(probe_dist[j / S]);
-                    uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
-                    while (true) {
-                        uint32_t kk = htk[slot];
-                        if (kk == kEmptyKey) {
-                            kk = atomicCAS(&htk[slot], kEmptyKey, static_cast<uint32_t>(id));
-                            if (kk == kEmptyKey) {  // created: bestScore.put(id, score) of a new key
-                                htv[slot] = (score << kSeqBits) | static_cast<uint32_t>(j);
-                                created++;
-                                break;
-                            }
-                        }
-                        if (kk == static_cast<uint32_t>(id)) {  // prev != null
-                            const uint32_t cur = htv[slot];
-                            if (score < (cur >> kSeqBits)) {      // score < prev -> put, position kept
-                                htv[slot] = (score << kSeqBits) | (cur & kSeqMask);
-                                touched++;
-                            }
-                            break;
-                        }
-                        slot = (slot + 1) & ht_mask;
-                    }
+            __syncthreads();
+            cut = s_cut;
+            if (cut != 0x7FFFFFFF) {  // entries and repeats behind the cut never existed
+                for (int j = tid; j < prm.max_tuples; j += nthreads) {
+                    const uint16_t v = tscore[j];
+                    if (!(v & kLiveFlag) || FSP_TS(j) <= cut) continue;
+                    if (v & kFirstFlag) atomicSub(&bins[v & 0x3FFF], 1);
+                    else atomicSub(&dupcnt[FSP_TS(j) / P], 1);
+                    tscore[j] = 0;
                 }
-                if (created) atomicAdd(&s_phase[phase % 3], created);
-                if (created + touched) atomicAdd(&s_raw, created + touched);
-                if (tid == 0) s_phase[(phase + 1) % 3] = 0;
                 __syncthreads();
-                size += s_phase[phase % 3];
-                phase++;
             }
         }
-        __syncthreads();
+        // n = number of live first occurrences
+        {
+            int c = 0;
+            for (int g = tid; g < TP; g += nthreads) if (g <= cut) c += stepcnt[g];
+            if (c) atomicAdd(&s_n, c);
+        }
+        FSP_STAMP(9);
 
-        // ---- phase C: order + select ----------------------------------------------
-        const int n = size;
-        const int capf = java_final_cap(prm.cap0, n);
-        const uint32_t bmask = static_cast<uint32_t>(capf - 1);
-        for (int i = tid; i < prm.ht_size; i += nthreads)
-            if (htk[i] != kEmptyKey) atomicAdd(&hist[htv[i] >> kSeqBits], 1);
-        __syncthreads();
-        if (tid == 0) {
-            int cum = 0, star = prm.nbins - 1;
-            if (n > prm.limit) {
-                for (int b = 0; b < prm.nbins; b++) {
-                    cum += hist[b];
-                    if (cum >= prm.limit) { star = b; break; }
+        // ---- B3: repeated occurrences: min score + strict improvements in table order (PIS:744-750) --
+        if (ndup > 0 && ndup <= kDupListMax) {
+            // all repeats in parallel: a repeat d improves iff its score is below the first occurrence's
+            // and below every earlier repeat of the same id; the overall minimum (earliest on ties) is
+            // the one that rewrites the entry's score.
+            for (int l = tid; l < ndup; l += nthreads) {
+                const int j = duplist[l];
+                if (!(tscore[j] & kLiveFlag)) continue;      // behind the HARD_CAP cut
+                const int32_t id = tup[j];
+                const int sc = probe[FSP_TS(j)].y;
+                const uint32_t f = ht[find_slot(id)];
+                const int first_sc = probe[FSP_TS(static_cast<int>(f))].y;
+                bool improves = sc < first_sc, is_min = improves;
+                for (int l2 = 0; l2 < ndup && (improves || is_min); l2++) {
+                    const int j2 = duplist[l2];
+                    if (j2 == j || tup[j2] != id || !(tscore[j2] & kLiveFlag)) continue;
+                    const int sc2 = probe[FSP_TS(j2)].y;
+                    if (j2 < j && sc2 <= sc) improves = false;
+                    if (sc2 < sc || (sc2 == sc && j2 < j)) is_min = false;
                 }
-            } else {
-                cum = n;
+                if (improves) atomicAdd(&s_raw, 1);
+                if (is_min) {  // unique writer per id
+                    tscore[f] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
+                    atomicSub(&bins[first_sc], 1);
+                    atomicAdd(&bins[sc], 1);
+                }
             }
-            s_star = star;
-            s_sel = cum;  // entries with score <= s*
+            __syncthreads();
+        } else if (ndup > kDupListMax) {
+            for (int td = 0; td < TD; td++) {   // table phases: an id occurs at most once per table
+                if (dupcnt[td] == 0) continue;  // uniform
+                int improved = 0;
+                const int j1 = (td * P + nprobe[td]) * S;
+                for (int j = td * P * S + tid; j < j1; j += nthreads) {
+                    const uint16_t v = tscore[j];
+                    if (!(v & kLiveFlag) || (v & kFirstFlag)) continue;
+                    const uint32_t f = ht[find_slot(tup[j])];
+                    const int sc = probe[FSP_TS(j)].y;
+                    const int old = tscore[f] & 0x3FFF;
+                    if (sc < old) {
+                        tscore[f] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
+                        atomicSub(&bins[old], 1);
+                        atomicAdd(&bins[sc], 1);
+                        improved++;
+                    }
+                }
+                if (improved) atomicAdd(&s_raw, improved);
+                __syncthreads();
+            }
+        } else {
+            __syncthreads();
         }
-        __syncthreads();
-        const int star = s_star, nsel = s_sel;
-        int n2 = 1;
-        while (n2 < nsel) n2 <<= 1;
-        const bool lds_sort_ok = (n2 <= prm.sort_cap_lds);
-        uint64_t* gs = prm.g_sort + static_cast<int64_t>(blockIdx.x) * prm.g_sort_stride;
-        for (int i = tid; i < prm.ht_size; i += nthreads) {
-            const uint32_t id = htk[i];
-            if (id == kEmptyKey) continue;
-            const uint32_t v = htv[i];
-            const uint32_t sc = v >> kSeqBits;
-            if (static_cast<int>(sc) > star) continue;
-            uint32_t h = static_cast<uint32_t>(prm.java_hash[id]);
-            h ^= (h >> 16);  // HashMap.hash(): spread
-            const uint64_t key = (static_cast<uint64_t>(sc) << (kBucketBits + kSeqBits)) |
-                                 (static_cast<uint64_t>(h & bmask) << kSeqBits) | (v & kSeqMask);
-            const int pos = atomicAdd(&s_fill, 1);
-            if (lds_sort_ok) lds_sort[pos] = key; else gs[pos] = key;
-        }
-        for (int i = nsel + tid; i < n2; i += nthreads) {
-            if (lds_sort_ok) lds_sort[i] = ~0ull; else gs[i] = ~0ull;
-        }
-        __syncthreads();
-        if (lds_sort_ok) bitonic_sort_u64(lds_sort, n2, tid, nthreads);
-        else bitonic_sort_u64(gs, n2, tid, nthreads);
+        FSP_STAMP(3);
 
-        const int nout = min(nsel, prm.limit);
-        for (int i = tid; i < nout; i += nthreads) {
-            const uint64_t key = lds_sort_ok ? lds_sort[i] : gs[i];
-            const int32_t id = tup[static_cast<uint32_t>(key) & kSeqMask];
-            prm.out_ids[qi * prm.out_cap + i] = id;
-            if (prm.out_score) prm.out_score[qi * prm.out_cap + i] = static_cast<int32_t>(key >> (kBucketBits + kSeqBits));
+        // ---- C: order + select -------------------------------------------------------------
+        const int n = s_n;
+        const int capf = java_final_cap(prm.cap0, n);
+        const int capbits = 31 - __clz(capf);
+        const uint32_t bmask = static_cast<uint32_t>(capf - 1);
+        const int bshift = kBucketBits - capbits;  // align the bucket's MSB with the 20-bit field
+        if (wave == 0) {  // level 0: cut score from the histogram
+            int star = prm.nbins - 1, need = 0x7FFFFFFF, tie = 0;
+            if (n > prm.limit) {
+                int before = 0;
+                star = wave_find_cut(bins, prm.nbins, prm.limit, lane, &before);
+                need = prm.limit - before;
+                tie = bins[star];
+            }
+            if (lane == 0) {
+                s_star = star;   // entries with score < star are all selected; `need` more come from score == star
+                s_need = need;
+                s_b1 = 0x7FFFFFFF;
+                s_lvl1 = (n > prm.limit && tie - need > 256) ? 1 : 0;  // worth cutting the tie group further
+            }
         }
+        __syncthreads();
+        const int star = s_star;
+        const bool lvl1 = (s_lvl1 != 0);
+        auto bucket_field = [&](int32_t id) -> uint32_t {
+            uint32_t h = prm.decimal_ids ? decimal_string_hash_dev(static_cast<uint32_t>(id))
+                                         : static_cast<uint32_t>(prm.java_hash[id]);
+            h ^= (h >> 16);  // HashMap.hash(): spread
+            return (h & bmask) << bshift;
+        };
+        if (lvl1) {
+            // level 1: tie group (score == star) by the top 10 bits of the HashMap bucket
+            for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;
+            __syncthreads();
+            for (int j = tid; j < prm.max_tuples; j += nthreads) {
+                const uint16_t v = tscore[j];
+                if (!(v & kFirstFlag) || (v & 0x3FFFu) != star) continue;
+                atomicAdd(&bins[bucket_field(tup[j]) >> (kBucketBits - 10)], 1);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                int before = 0;
+                const int b1v = wave_find_cut(bins, 1024, s_need, lane, &before);
+                if (lane == 0) s_b1 = b1v;
+            }
+            __syncthreads();
+        }
+        const int b1 = s_b1;
+        FSP_STAMP(11);
+        // compaction of the surviving candidates: score < star, or score == star && bucket bin <= b1
+        uint64_t* gs = prm.g_sort ? prm.g_sort + static_cast<int64_t>(blockIdx.x) * prm.g_sort_stride : sortbuf;
+        for (int j = tid; j < prm.max_tuples; j += nthreads) {
+            const uint16_t v = tscore[j];
+            if (!(v & kFirstFlag)) continue;
+            const int sc = v & 0x3FFFu;
+            if (sc > star) continue;
+            const uint32_t bfield = bucket_field(tup[j]);
+            if (sc == star && lvl1 && static_cast<int>(bfield >> (kBucketBits - 10)) > b1) continue;
+            const uint64_t key = (static_cast<uint64_t>(sc) << (kBucketBits + kSeqBits)) |
+                                 (static_cast<uint64_t>(bfield) << kSeqBits) | static_cast<uint32_t>(j);
+            const int pos = atomicAdd(&s_fill, 1);
+            if (pos < prm.sort_cap) sortbuf[pos] = key;
+            else gs[pos] = key;  // only reachable when g_sort exists (host guarantees capacity)
+        }
+        __syncthreads();
+        FSP_STAMP(4);
+        const int nsel = s_fill;
+        if (tid == 0 && prm.dbg && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + 15] = nsel;
+        const int nout = min(nsel, prm.limit);
+        if (nsel <= kRankSortMax - 128 && prm.sort_cap >= kRankSortMax) {
+            // all-pairs rank: keys are unique (seq is), so rank = #smaller keys; no barriers.
+            // element i is ranked by `parts` cooperating lanes, each over a slice of j.
+            // slices of 8 keys are read with four 16-byte LDS loads issued back to back.
+            int parts = 1;
+            while (parts < 16 && nsel * parts * 2 <= nthreads * 2) parts <<= 1;
+            const int len = (((nsel + parts - 1) / parts) + 7) & ~7;   // slice length, multiple of 8
+            const int padded = parts * len;                            // <= sort_cap by construction (host: sort_cap >= 1024)
+            for (int i = nsel + tid; i < padded; i += nthreads) sortbuf[i] = ~0ull;  // sentinels never count
+            __syncthreads();
+            const int per_pass = nthreads / parts;
+            for (int base = 0; base < nsel; base += per_pass) {
+                const int i = base + tid / parts, part = tid % parts;
+                uint64_t key = 0;
+                int rank = 0;
+                if (i < nsel) {
+                    key = sortbuf[i];
+                    const ulonglong2* sb2 = reinterpret_cast<const ulonglong2*>(sortbuf + part * len);
+                    for (int j = 0; j < len / 2; j += 4) {
+                        const ulonglong2 k0 = sb2[j], k1 = sb2[j + 1], k2 = sb2[j + 2], k3 = sb2[j + 3];
+                        rank += (k0.x < key) + (k0.y < key) + (k1.x < key) + (k1.y < key) +
+                                (k2.x < key) + (k2.y < key) + (k3.x < key) + (k3.y < key);
+                    }
+                }
+                for (int off = parts >> 1; off > 0; off >>= 1) rank += __shfl_xor(rank, off);
+                if (i < nsel && part == 0 && rank < nout) {
+                    prm.out_ids[qi * prm.out_cap + rank] = tup[static_cast<uint32_t>(key) & kSeqMask];
+                    if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = static_cast<int32_t>(key >> (kBucketBits + kSeqBits));
+                }
+            }
+        } else {
+            int n2 = 1;
+            while (n2 < nsel) n2 <<= 1;
+            const bool in_lds_buf = (n2 <= prm.sort_cap);
+            if (!in_lds_buf) {  // gather everything into the global buffer
+                for (int i = tid; i < min(nsel, prm.sort_cap); i += nthreads) gs[i] = sortbuf[i];
+            }
+            uint64_t* sb = in_lds_buf ? sortbuf : gs;
+            for (int i = nsel + tid; i < n2; i += nthreads) sb[i] = ~0ull;
+            __syncthreads();
+            if (in_lds_buf) bitonic_sort_u64(sortbuf, n2, tid, nthreads);
+            else bitonic_sort_u64(gs, n2, tid, nthreads);
+            for (int i = tid; i < nout; i += nthreads) {
+                const uint64_t key = sb[i];
+                prm.out_ids[qi * prm.out_cap + i] = tup[static_cast<uint32_t>(key) & kSeqMask];
+                if (prm.out_score) prm.out_score[qi * prm.out_cap + i] = static_cast<int32_t>(key >> (kBucketBits + kSeqBits));
+            }
+        }
+        FSP_STAMP(5);
         if (tid == 0) {
             prm.out_count[qi] = nout;
             if (prm.out_kept) prm.out_kept[qi] = n;
-            if (prm.out_raw) prm.out_raw[qi] = s_raw;
+            if (prm.out_raw) prm.out_raw[qi] = n + s_raw;
         }
         __syncthreads();
+        FSP_STAMP(6);
     }
+#undef FSP_STAMP
+#undef FSP_TS
 }
 
 }  // namespace fspann
