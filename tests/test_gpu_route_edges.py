@@ -1,0 +1,160 @@
+"""GPU parity, Route edge cases: every rarely-taken path of the route kernels against the oracle.
+
+  * HARD_CAP triggering mid-table / mid-probe (PIS:612-615,624,628,657-659)
+  * deleted ids (PIS:736-742)
+  * heavy repeats across tables (clustered data: > kDupListMax repeats -> table-phase path)
+  * tiny tables (fewer partitions than probes), one-partition tables
+  * many probes (retry P = 10, fallback P = 20), W = 2..3 code words
+  * per-query scratch that does not fit LDS (global arena path)
+  * arbitrary String ids (java_hash given explicitly)
+"""
+import numpy as np
+import pytest
+
+from conftest import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def ctx_for(pkg, sc, java_hash=None, **over):
+    p = dict(sc["params"])
+    p.update(over)
+    cfg = pkg.PaperRuntimeConfig(tables=p["T"], divisions=p["D"], m=p["m"], lambda_=p["lam"], dim=p["d"],
+                                 refinement_limit=p["B"], max_global_candidates=p["hard_cap"],
+                                 probe_override=p["probe_override"], hamming_prefilter_threshold=p["tau"])
+    ctx = pkg.FspannContext(cfg, 0)
+    ctx.set_gfunctions(sc["alpha"], sc["r"], sc["omega"])
+    ctx.set_id_meta(p["n"], java_hash, sc["deleted"])
+    return ctx
+
+
+def check_route(pkg, sc, nq=16, probes=-1, limits=(None,), java_hash=None, import_index=False):
+    o = sc["oracle"]
+    p = sc["params"]
+    Q = sc["rng"].standard_normal((nq, p["d"])).astype(np.float32).astype(np.float64)
+    if p.get("clustered"):
+        Q = 5 + 0.1 * Q
+    codes = o.encode(Q)
+    ids, score, count, raw = o.route(codes, probe_override=probes)
+    assert not o.unmodelled, "oracle HashMap treeified: order not pinned for this scene"
+    with ctx_for(pkg, sc, java_hash=java_hash) as ctx:
+        if import_index:
+            for td in range(o.TD):
+                ctx.set_index(td, **o.get_index(td))
+            ctx.finalize()
+        else:
+            ctx.build_index(sc["X"])
+        for lim in limits:
+            res = ctx.route(codes, probe_override=probes, limit=lim if lim else 2**31 - 1)
+            assert np.array_equal(res["kept"], count)
+            assert np.array_equal(res["raw_seen"], raw)
+            for i in range(nq):
+                n = count[i] if not lim else min(lim, count[i])
+                assert res["count"][i] == n
+                assert np.array_equal(res["ids"][i, :n], ids[i, :n]), (lim, i)
+                assert np.array_equal(res["score"][i, :n], score[i, :n]), (lim, i)
+    return count, raw
+
+
+def test_hard_cap_triggers(pkg, oracle):
+    # T*D*P*S = 6*1*5*64 = 1920 tuples against HARD_CAP = 700: stops in the middle of a table
+    sc = make_scene(oracle, n=6000, d=16, T=6, D=1, m=10, lam=2, B=100, hard_cap=700, seed=5)
+    count, _ = check_route(pkg, sc, limits=(None, 100, 700))
+    assert count.max() >= 700 and count.max() <= 700 + 63
+    # cap a few ids above a multiple of the block size / exactly at the first probe
+    for cap in (64, 65, 129, 320, 321):
+        sc = make_scene(oracle, n=3000, d=12, T=4, D=2, m=8, lam=2, B=40, hard_cap=cap, seed=cap)
+        check_route(pkg, sc, limits=(None, 40))
+
+
+def test_hard_cap_with_probe_overrides(pkg, oracle):
+    sc = make_scene(oracle, n=8000, d=16, T=4, D=2, m=12, lam=2, B=256, hard_cap=1500, seed=9)
+    for probes in (1, 3, 10, 20):
+        check_route(pkg, sc, probes=probes, limits=(None, 256))
+
+
+def test_deleted_ids(pkg, oracle):
+    sc = make_scene(oracle, n=5000, d=16, T=4, D=2, m=10, lam=2, B=128, deleted_frac=0.3, seed=11)
+    check_route(pkg, sc, limits=(None, 128))
+    sc = make_scene(oracle, n=2000, d=8, T=3, D=1, m=8, lam=2, B=64, deleted_frac=0.97, seed=12)
+    check_route(pkg, sc, limits=(None, 64))
+
+
+def test_heavy_repeats_clustered(pkg, oracle):
+    # tight cluster: all tables probe nearly the same ids -> thousands of repeated occurrences
+    sc = make_scene(oracle, n=1024, d=8, T=4, D=4, m=4, lam=3, B=128, clustered=True, seed=13)
+    sc["params"]["clustered"] = True
+    count, raw = check_route(pkg, sc, limits=(None, 128, 10))
+    assert (raw > count).any()
+
+
+def test_heavy_repeats_same_gfunction(pkg, oracle):
+    # identical tables: every id repeats T*D times with equal scores (no strict improvement)
+    sc = make_scene(oracle, n=3000, d=10, T=3, D=2, m=8, lam=2, B=64, seed=14)
+    a, r, w = sc["alpha"], sc["r"], sc["omega"]
+    a[:] = a[0]
+    r[:] = r[0]
+    w[:] = w[0]
+    o = sc["oracle"]
+    o.set_gfunctions(a, r, w)
+    o.build_index(sc["X64"])
+    count, raw = check_route(pkg, sc, limits=(None, 64))
+    assert np.array_equal(count, raw)  # repeats never improve
+
+
+def test_tiny_tables(pkg, oracle):
+    for n in (1, 5, 64, 65, 130):
+        sc = make_scene(oracle, n=n, d=4, T=2, D=2, m=4, lam=2, B=33, seed=20 + n)
+        check_route(pkg, sc, nq=6, limits=(None, 33, 1))
+        check_route(pkg, sc, nq=6, probes=10, limits=(None,))
+
+
+def test_wide_codes(pkg, oracle):
+    sc = make_scene(oracle, n=4000, d=20, T=2, D=2, m=40, lam=3, B=100, seed=31)   # 120 bits -> W = 2
+    check_route(pkg, sc, limits=(None, 100))
+    sc = make_scene(oracle, n=3000, d=20, T=2, D=1, m=80, lam=2, B=100, seed=32)   # 160 bits -> W = 3
+    check_route(pkg, sc, limits=(None, 100))
+    sc = make_scene(oracle, n=3000, d=12, T=2, D=2, m=31, lam=2, B=50, seed=33)    # 62 bits
+    check_route(pkg, sc, limits=(None, 50))
+    sc = make_scene(oracle, n=3000, d=12, T=2, D=2, m=32, lam=2, B=50, seed=34)    # 64 bits: bit 63 is not in the key
+    check_route(pkg, sc, limits=(None, 50))
+
+
+def test_global_arena_path(pkg, oracle):
+    # 10 tables x 4 divisions x 20 probes x 64 = 51200 tuple slots: per-query scratch exceeds LDS
+    sc = make_scene(oracle, n=20000, d=16, T=10, D=4, m=12, lam=2, B=512, hard_cap=60000, seed=41)
+    count, _ = check_route(pkg, sc, nq=6, probes=20, limits=(None, 512))
+    assert count.max() > 8192
+    # same with a HARD_CAP cut inside
+    sc = make_scene(oracle, n=20000, d=16, T=10, D=4, m=12, lam=2, B=512, hard_cap=9000, seed=42)
+    check_route(pkg, sc, nq=6, probes=20, limits=(None, 512))
+
+
+def test_long_lists_sorted_in_lds_and_global(pkg, oracle):
+    # full lists of ~3-4k entries (LDS bitonic) and ~20k entries (global bitonic)
+    sc = make_scene(oracle, n=20000, d=16, T=8, D=1, m=12, lam=2, B=4000, seed=51)
+    check_route(pkg, sc, nq=8, probes=10, limits=(None, 4000, 1500))
+    sc = make_scene(oracle, n=60000, d=16, T=8, D=4, m=14, lam=2, B=20000, hard_cap=30000, seed=52)
+    check_route(pkg, sc, nq=4, probes=10, limits=(None, 20000))
+
+
+def test_string_ids_via_java_hash(pkg, oracle):
+    """Arbitrary String ids: the adapter hands String.hashCode per handle (fspann_set_id_meta)."""
+    n = 4000
+    sc = make_scene(oracle, n=n, d=12, T=3, D=2, m=10, lam=2, B=64, seed=61)
+    names = ["vec-%05x-%d" % (i * 2654435761 % (1 << 20), i) for i in range(n)]
+    jh = np.array([oracle.string_hash(s) for s in names], dtype=np.int32)
+    o = sc["oracle"]
+    o.set_id_meta(n, jh, None)
+    o.build_index(sc["X64"])
+    check_route(pkg, sc, limits=(None, 64), java_hash=jh)
+
+
+def test_imported_index_equals_native_build(pkg, oracle):
+    sc = make_scene(oracle, n=5000, d=16, T=3, D=3, m=10, lam=2, B=99, seed=71)
+    check_route(pkg, sc, limits=(None, 99), import_index=True)
+
+
+def test_batch_larger_than_grid(pkg, oracle):
+    sc = make_scene(oracle, n=3000, d=8, T=2, D=2, m=8, lam=2, B=32, seed=81)
+    check_route(pkg, sc, nq=1500, limits=(32,))
