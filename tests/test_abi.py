@@ -1,0 +1,102 @@
+"""CPU: the C-ABI library loads and exports every symbol include/fspann.h declares; error
+mapping and host-side argument checks that need no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "fspann.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fspann_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    pkg._native.build()
+    L = pkg._native.lib()
+    syms = header_symbols()
+    assert len(syms) >= 28
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/fspann.h but not exported"
+    # and the binding table covers the header (no silent drift)
+    assert set(pkg._native.exported_symbols()) == set(syms)
+
+
+def test_version_and_error_string(pkg):
+    L = pkg._native.lib()
+    assert b"gfx950" in L.fspann_version()
+    assert isinstance(L.fspann_last_error(), bytes)
+
+
+def test_null_and_argument_errors_without_gpu(pkg):
+    N = pkg._native
+    L = N.lib()
+    h = C.c_void_p()
+    assert L.fspann_ctx_create(0, None, C.byref(h)) == N.E_NULL
+    bad = N.Cfg(0, 1, 8, 2, 16, 0, 0, -1, 0, 0, 0, 0)
+    assert L.fspann_ctx_create(0, C.byref(bad), C.byref(h)) == N.E_ARG
+    assert b"> 0" in L.fspann_last_error()
+    bad = N.Cfg(2, 1, 8, 40, 16, 0, 0, -1, 0, 0, 0, 0)          # lambda > 32
+    assert L.fspann_ctx_create(0, C.byref(bad), C.byref(h)) == N.E_ARG
+    assert L.fspann_sync(None) == N.E_NULL
+    assert L.fspann_encode(None, 1, None, 0, None, None) == N.E_NULL
+    with pytest.raises(N.FspannNullError):
+        N.check(N.E_NULL)
+    with pytest.raises(ValueError):      # IllegalArgumentException is a ValueError
+        N.check(N.E_ARG)
+
+
+def test_no_gpu_means_device_error_not_fallback(pkg):
+    """The product path must fail loudly without a GPU: there is no CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.FspannDeviceError):
+        pkg.FspannContext(pkg.PaperRuntimeConfig(tables=2, divisions=1, m=8, lambda_=2, dim=16), 0)
+
+
+def test_product_never_imports_oracle():
+    pkgdir = os.path.join(ROOT, "fspann-query-system_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+                assert "fspann_oracle" not in txt, f
+
+
+def test_operator_surface_host_checks(pkg):
+    from fspann_amd import operators as ops
+    N = pkg._native
+    host = ops.InMemoryHost()
+    cfg = ops.SystemConfig(m=8, lambda_=2, divisions=1, tables=2)
+    ops.GFunctionRegistry.reset()
+    tf = ops.QueryTokenFactory(host, host, cfg)
+    with pytest.raises(N.FspannNullError):           # Objects.requireNonNull(vec)
+        tf.create(None, 5)
+    with pytest.raises(N.FspannArgumentError):       # topK must be > 0
+        tf.create(np.zeros(4), 0)
+    with pytest.raises(N.FspannStateError):          # registry not initialised
+        tf.create(np.zeros(4), 5)
+    with pytest.raises(N.FspannNullError):
+        ops.PartitionedIndexService(None, cfg, host, host)
+    idx = ops.PartitionedIndexService(host, cfg, host, host)
+    tok = ops.QueryToken(np.zeros((2, 1, 1), np.uint64), b"0" * 12, b"", 5, 2, 4, 1, 2, "dim_4_v1")
+    with pytest.raises(N.FspannStateError):          # "Index not finalized" (PIS:594)
+        idx.lookupCandidatesWithScores(tok)
+    with pytest.raises(N.FspannStateError):          # cannot finalize with < 1000 samples and no registry
+        idx.finalizeForSearch()
+    with pytest.raises(N.FspannNullError):
+        idx.insert(None, np.zeros(4))
+    qs = ops.QueryServiceImpl(idx, host, host, tf, cfg)
+    assert qs.search(None) == []                     # null token -> empty list (QSI:102)
+    with pytest.raises(N.FspannArgumentError):
+        tf.derive(tok, 0)
+    t2 = tf.derive(tok, 7)
+    assert t2.getTopK() == 7 and np.array_equal(t2.getBitCodes(), tok.getBitCodes())
+    assert ops._java_string_hash("hello") == 99162322 and ops._java_string_hash("1000000") == 1958013297

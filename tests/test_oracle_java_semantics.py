@@ -1,0 +1,177 @@
+"""CPU: micro known-answer tests that pin the oracle's JDK models.
+
+The reference ships no golden vectors for this path and no JVM exists in the build
+container, so these KATs use published / hand-derived values only:
+  * SplitMix64 (java.util.SplittableRandom): reference outputs for seed 0
+  * String.hashCode: documented formula + well-known values
+  * (int) double cast: JLS 5.1.3
+  * HashMap.tableSizeFor / iteration order: derived by hand from the JDK algorithm
+  * PriorityQueue: binary-heap siftUp/siftDown tie behaviour
+"""
+import numpy as np
+
+
+def test_splitmix64_seed0(oracle):
+    # published SplitMix64 test vector (state 0): first three outputs
+    assert oracle.splitmix_stream(0, 3) == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+def test_nextdouble_is_top53_bits(oracle):
+    for seed in (0, 13, 42, 12345):
+        longs = oracle.splitmix_stream(seed, 5)
+        dbls = oracle.splitmix_doubles(seed, 5)
+        for L, d in zip(longs, dbls):
+            assert d == (L >> 11) * 2.0 ** -53
+            assert 0.0 <= d < 1.0
+
+
+def test_string_hashcode(oracle):
+    assert oracle.string_hash("") == 0
+    assert oracle.string_hash("a") == 97
+    assert oracle.string_hash("hello") == 99162322
+    assert oracle.string_hash("0") == 48
+    assert oracle.string_hash("10") == 49 * 31 + 48
+    # int32 wrap-around
+    s = "polygenelubricants"
+    h = 0
+    for ch in s:
+        h = (31 * h + ord(ch)) & 0xFFFFFFFF
+    h = h - (1 << 32) if h & 0x80000000 else h
+    assert oracle.string_hash(s) == h
+    hs = oracle.decimal_hashes(1001)
+    assert hs[0] == 48 and hs[999] == oracle.string_hash("999") and hs[1000] == oracle.string_hash("1000")
+
+
+def test_saturating_int_cast(oracle):
+    assert oracle.d2i(float("nan")) == 0
+    assert oracle.d2i(1e300) == 2**31 - 1
+    assert oracle.d2i(-1e300) == -2**31
+    assert oracle.d2i(2147483647.0) == 2**31 - 1
+    assert oracle.d2i(-2147483648.0) == -2**31
+    assert oracle.d2i(-3.0) == -3 and oracle.d2i(3.0) == 3
+    assert oracle.d2i(float("inf")) == 2**31 - 1
+
+
+def test_table_size_for(oracle):
+    assert [oracle.table_size_for(c) for c in (0, 1, 2, 3, 4, 5, 16, 17, 1000, 20000, 65536, 65537)] == \
+        [1, 1, 2, 4, 4, 8, 16, 32, 1024, 32768, 65536, 131072]
+
+
+def test_hashmap_iteration_order_small(oracle):
+    # new HashMap<>(16): buckets = spread(h) & 15; chain order = insertion order
+    keys = np.arange(6, dtype=np.int32)
+    hashes = np.array([17, 1, 33, 2, 16, 0], dtype=np.int32)  # buckets 1,1,1,2,0,0
+    out, cap, unm = oracle.hashmap_order(16, keys, hashes)
+    assert cap == 16 and not unm
+    assert list(out) == [4, 5, 0, 1, 2, 3]
+
+
+def test_hashmap_resize_preserves_relative_order(oracle):
+    # cap 4 (threshold 3): 4th insert resizes to 8; keys with hash 1 and 5 shared bucket 1, then split
+    keys = np.arange(5, dtype=np.int32)
+    hashes = np.array([5, 1, 9, 13, 2], dtype=np.int32)
+    out, cap, unm = oracle.hashmap_order(4, keys, hashes)
+    assert cap == 8 and not unm
+    # cap 8 buckets: 5->5, 1->1, 9->1, 13->5, 2->2  => bucket1: [1(h=1), 2(h=9)], bucket2: [4], bucket5: [0, 3]
+    assert list(out) == [1, 2, 4, 0, 3]
+
+
+def test_hashmap_spread_uses_high_bits(oracle):
+    # h ^ (h >>> 16): 0x10000 -> bucket 1 in a 16-table, 0x20000 -> bucket 2
+    keys = np.arange(3, dtype=np.int32)
+    hashes = np.array([0x20000, 0x10000, 0], dtype=np.int32)
+    out, cap, _ = oracle.hashmap_order(16, keys, hashes)
+    assert list(out) == [2, 1, 0]
+
+
+def test_hashmap_small_table_resizes_instead_of_treeifying(oracle):
+    # 9 colliding keys in a 16-table: treeifyBin() with tab.length < 64 calls resize()
+    keys = np.arange(9, dtype=np.int32)
+    hashes = np.array([16 * i for i in range(9)], dtype=np.int32)  # all bucket 0 at cap 16
+    out, cap, unm = oracle.hashmap_order(16, keys, hashes)
+    assert not unm and cap == 32
+    # at cap 32: hashes with bit 16 clear stay in bucket 0 (0,32,64,96,128), the others go to 16
+    assert list(out) == [0, 2, 4, 6, 8, 1, 3, 5, 7]
+
+
+def test_hashmap_flags_real_treeification(oracle):
+    keys = np.arange(9, dtype=np.int32)
+    hashes = np.array([64 * i for i in range(9)], dtype=np.int32)
+    _, cap, unm = oracle.hashmap_order(64, keys, hashes)
+    assert unm and cap == 64
+
+
+def test_priority_queue_ties(oracle):
+    # ops[i] >= 0: add(idx=i, dist=ops[i]); -1: poll
+    # PIS probe pattern: add center; poll; add left, add right (equal dist) -> left first (queued first, strict <)
+    assert list(oracle.pq_trace([5, -1, 3, 3, -1, -1])) == [0, 2, 3]
+    # survivor vs newcomer with equal dist: the survivor (older) wins
+    assert list(oracle.pq_trace([5, -1, 3, 4, -1, 4, -1, -1])) == [0, 2, 3, 5]
+    # strictly smaller newcomer wins
+    assert list(oracle.pq_trace([5, -1, 3, 4, -1, 2, -1, -1])) == [0, 2, 5, 3]
+
+
+def test_compute_key_and_hamming(oracle):
+    w = np.array([0b1011], dtype=np.uint64)  # bits 0,1,3 set -> key bits 62,61,59
+    assert oracle.compute_key(w) == (1 << 62) | (1 << 61) | (1 << 59)
+    w2 = np.array([1 << 63, 1], dtype=np.uint64)  # bit 63 and 64 are outside the 63-bit key
+    assert oracle.compute_key(w2) == 0
+    assert oracle.hamming(np.array([0xFF, 1], np.uint64), np.array([0x0F, 0], np.uint64)) == 5
+
+
+def test_coding_quickcheck_property(oracle):
+    """index/src/test/java/com/fspann/index/CodingQuickCheck.java:10-37 — the one property
+    the reference's own tests pin: bit 0 of C(v) == bit (lambda-1) of H[0]."""
+    rc, h0, bit0 = oracle.quickcheck()
+    assert rc == 0
+    assert bit0 == ((h0 & 0xFFFFFFFF) >> 1) & 1
+
+
+def test_coding_bit_layout(oracle):
+    # C(v): pos = (lambda-1-i)*m + j <- bit i of h_j; check against H on a random GFunction
+    rng = np.random.default_rng(3)
+    d, m, lam = 12, 7, 3
+    alpha, r, w = oracle.build_random_g(d, m, 1.0, 99)
+    assert np.allclose(np.linalg.norm(alpha, axis=1), 1.0)
+    assert np.all((r >= 0) & (r < 1.0)) and np.all(w == 1.0)
+    for _ in range(20):
+        v = rng.standard_normal(d) * 3
+        H = oracle.H(v, alpha, r, w)
+        code = int(oracle.Ccode(v, alpha, r, w, lam)[0])
+        for i in range(lam):
+            for j in range(m):
+                pos = (lam - 1 - i) * m + j
+                assert (code >> pos) & 1 == ((int(H[j]) & 0xFFFFFFFF) >> i) & 1
+        assert code >> (m * lam) == 0
+        # H itself: floor((alpha_j . v + r_j) / omega_j) with a sequential fp64 sum
+        for j in range(m):
+            acc = 0.0
+            for i in range(d):
+                acc += v[i] * alpha[j, i]
+            assert H[j] == int(np.floor((acc + r[j]) / w[j]))
+
+
+def test_build_from_sample_omega(oracle):
+    rng = np.random.default_rng(4)
+    S = rng.standard_normal((200, 9))
+    alpha, r, w = oracle.build_from_sample(S, 5, 77)
+    a2, _, _ = oracle.build_random_g(9, 5, 1.0, 77)
+    assert np.array_equal(alpha, a2)  # same draw order for alpha
+    for j in range(5):
+        ys = []
+        for v in S:
+            acc = 0.0
+            for i in range(9):
+                acc += v[i] * alpha[j, i]
+            ys.append(acc)
+        assert w[j] == max(1e-6, max(ys) - min(ys)) / 2.5
+        assert 0 <= r[j] < w[j]
+
+
+def test_nan_vector_rejected(oracle):
+    alpha, r, w = oracle.build_random_g(4, 3, 1.0, 1)
+    import pytest
+    with pytest.raises(ValueError):
+        oracle.H(np.array([0.0, np.nan, 0, 0]), alpha, r, w)
+    with pytest.raises(ValueError):
+        oracle.Ccode(np.array([0.0, np.inf, 0, 0]), alpha, r, w, 2)
