@@ -68,9 +68,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the collective runs even at N = 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = graft.load_package()
     wl = dict(WORKLOADS[args.workload])
@@ -107,7 +109,8 @@ def main():
     out_dist = torch.zeros((Q, k), dtype=torch.float64, device=dev)
     out_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
     scored = torch.zeros(Q, dtype=torch.int32, device=dev)
-    gathered = torch.zeros((world, Q, k, 2), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros((world * Q, k, 2), dtype=torch.float64, device=dev) if use_dist else None
+    from fspann_amd import dist as fdist
     torch.cuda.synchronize()
 
     stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
@@ -132,16 +135,15 @@ def main():
                        out_ids.data_ptr(), out_dist.data_ptr(), out_cnt.data_ptr(), scored.data_ptr())
         if events is not None:
             events[4].record(stream)
-        if world > 1:
+        if use_dist:
             # the one collective of the path: all-gather of [Q x k] (id, dist) per rank over RCCL/xGMI
             with torch.cuda.stream(stream):
-                packed = torch.stack((out_ids.to(torch.float64), out_dist), dim=-1)
-                dist.all_gather_into_tensor(gathered.view(world * Q, k, 2), packed)
+                fdist.allgather_topk(out_ids, out_dist, out=gathered)
 
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -155,10 +157,10 @@ def main():
         step(evs[i])
     ctx.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -259,8 +261,11 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    if use_dist and rank == 0:
+        # merged result = every rank's top-k in rank order; rank 0's own slice must be intact
+        assert torch.equal(gathered[:Q, :, 0].to(torch.int32), out_ids)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
