@@ -172,11 +172,10 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     return FSPANN_OK;
 }
 
-template <typename TC, typename TQ>
-int launch_refine_t(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int64_t B, const int32_t* cand_ids,
-                    const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
-                    int32_t* scored) {
-    constexpr int DC = (sizeof(TC) == 4) ? 32 : 16;
+template <typename TC, typename TQ, int DC>
+int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int64_t B, const int32_t* cand_ids,
+                     const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
+                     int32_t* scored) {
     constexpr int VN = VecOf<TC>::N;
     const int d = c->cfg.dim;
     const int nchunks = static_cast<int>((B + kRefRows - 1) / kRefRows);
@@ -191,7 +190,7 @@ int launch_refine_t(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int6
         pcnt = reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_refine.p) + ((pb + 15) & ~size_t(15)));
     }
     const bool vec = (d % VN == 0) && ((reinterpret_cast<uintptr_t>(cand) & 15) == 0);
-    const size_t lds = static_cast<size_t>((d + 1) & ~1) * 8 + static_cast<size_t>(DC) * (kRefRows + 1) * sizeof(TC);
+    const size_t lds = static_cast<size_t>((d + 1) & ~1) * 8 + static_cast<size_t>(kRefRows) * (vec ? DC + VN : DC + 1) * sizeof(TC);
     const unsigned grid = static_cast<unsigned>(nq * nchunks);
     if (vec) {
         auto kern = refine_scan_kernel<TC, TQ, DC, true>;
@@ -211,6 +210,17 @@ int launch_refine_t(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int6
         FSP_HIP(hipGetLastError());
     }
     return FSPANN_OK;
+}
+
+template <typename TC, typename TQ>
+int launch_refine_t(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int64_t B, const int32_t* cand_ids,
+                    const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
+                    int32_t* scored) {
+    constexpr int DC0 = (sizeof(TC) == 4) ? 32 : 16;
+    static const int dc_env = [] { const char* e = getenv("FSPANN_REFINE_DC"); return e ? atoi(e) : 0; }();
+    if (dc_env == DC0 * 2) return launch_refine_dc<TC, TQ, DC0 * 2>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
+    if (dc_env == DC0 * 4) return launch_refine_dc<TC, TQ, DC0 * 4>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
+    return launch_refine_dc<TC, TQ, DC0>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
 }
 
 #define CHECK_CTX(c)                                                      \

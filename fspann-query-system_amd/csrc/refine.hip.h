@@ -31,120 +31,194 @@ struct RefinePartial {  // one per (query, chunk, rank)
 };
 
 template <typename T> struct VecOf;
-template <> struct VecOf<float> { using type = float4; static constexpr int N = 4; };
-template <> struct VecOf<double> { using type = double2; static constexpr int N = 2; };
+// native clang vectors (plain SSA values: a HIP float4 staging array ends up in scratch)
+typedef float fsp_f32x4 __attribute__((ext_vector_type(4)));
+typedef double fsp_f64x2 __attribute__((ext_vector_type(2)));
+template <> struct VecOf<float> { using type = fsp_f32x4; static constexpr int N = 4; };
+template <> struct VecOf<double> { using type = fsp_f64x2; static constexpr int N = 2; };
 
 template <typename T> __device__ __forceinline__ bool finite_t(T x) {
     return fabs(static_cast<double>(x)) <= 1.79769313486231570815e+308;
 }
 
+__device__ __forceinline__ double vcomp(fsp_f32x4 v, int e) { return static_cast<double>(v[e]); }
+__device__ __forceinline__ double vcomp(fsp_f64x2 v, int e) { return v[e]; }
+
+constexpr int kRefFilterMaxK = 32;   // top-k via per-wave k-th-smallest filter up to this k
+
+// rank of (key, pos) among keys[0..n): #{j : key_j < key || (key_j == key && j < pos)}; keys are read two
+// at a time (16-byte LDS loads); n is padded to an even count with kInvalidKey by the caller.
+__device__ __forceinline__ int rank_among(const uint64_t* keys, int n, uint64_t key, int pos) {
+    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);
+    int rank = 0;
+#pragma unroll 4
+    for (int j = 0; j < n / 2; j++) {
+        const ulonglong2 kk = k2[j];
+        rank += (kk.x < key) || (kk.x == key && 2 * j < pos);
+        rank += (kk.y < key) || (kk.y == key && 2 * j + 1 < pos);
+    }
+    return rank;
+}
+
 // TC = candidate dtype, TQ = query dtype, DC = dims per LDS tile, VEC = use 16-B loads.
+// LDS tile is ROW-major with a 16-byte pad per row (pitch DC*sizeof(TC)+16): the 16-byte writes of
+// 8 consecutive lanes fill one row segment, and lane r's 16-byte reads of ITS row hit banks
+// (36 r + 4 kk) mod 64 -> conflict-free for ds_read_b128 / ds_write_b128 (MI355X_MICROARCH.md §LDS).
 template <typename TC, typename TQ, int DC, bool VEC>
-__global__ __launch_bounds__(kRefRows) void refine_scan_kernel(
+__global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeof(TC) <= 256 ? 2 : 1))) void refine_scan_kernel(
     const TQ* __restrict__ q, const TC* __restrict__ cand, int64_t B, int d, const int32_t* __restrict__ cand_ids,
     const int32_t* __restrict__ cand_count, int k, int nchunks, int32_t* __restrict__ out_ids,
     double* __restrict__ out_dist, int32_t* __restrict__ out_count, int32_t* __restrict__ scored,
     RefinePartial* __restrict__ partial, int32_t* __restrict__ partial_cnt) {
-    constexpr int LD = kRefRows + 1;  // +1 word pad: conflict-light transposed writes
+    using V = typename VecOf<TC>::type;
+    constexpr int VN = VecOf<TC>::N;
+    constexpr int PITCH = VEC ? DC + VN : DC + 1;   // elements per LDS row
+    constexpr int VPR = DC / VN;                    // 16-byte vectors per row per tile
     extern __shared__ __align__(16) unsigned char smem[];
-    double* qs = reinterpret_cast<double*>(smem);                     // [d]
-    TC* tile = reinterpret_cast<TC*>(smem + static_cast<size_t>((d + 1) & ~1) * 8);  // [DC][LD]
-    __shared__ uint64_t keys[kRefRows];
-    __shared__ int s_qbad;
-    __shared__ int s_nvalid;
+    double* qs = reinterpret_cast<double*>(smem);                                        // [d], padded to even
+    TC* tile = reinterpret_cast<TC*>(smem + static_cast<size_t>((d + 1) & ~1) * 8);      // [kRefRows][PITCH]
+    __shared__ __align__(16) uint64_t keys[kRefRows];
+    __shared__ __align__(16) uint64_t surv[kRefRows];
+    __shared__ uint64_t s_wcut[kRefRows / 64];
+    __shared__ int s_qbad, s_nvalid;
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t qi = blockIdx.x / nchunks;
     const int chunk = blockIdx.x - static_cast<int>(qi) * nchunks;
-    const int cnt = min(static_cast<int64_t>(cand_count[qi]), B);
+    const int cnt = static_cast<int>(min(static_cast<int64_t>(cand_count[qi]), B));
     const int r0 = chunk * kRefRows;
     const int nrows = max(0, min(kRefRows, cnt - r0));
     const TC* base = cand + (qi * B + r0) * static_cast<int64_t>(d);
 
     if (tid == 0) { s_qbad = 0; s_nvalid = 0; }
     __syncthreads();
-    for (int i = tid; i < d; i += kRefRows) {
-        const TQ v = q[qi * d + i];
-        if (!finite_t(v)) s_qbad = 1;
-        qs[i] = static_cast<double>(v);
+    for (int i = tid; i < ((d + 1) & ~1); i += kRefRows) {
+        double v = 0.0;
+        if (i < d) {
+            const TQ x = q[qi * d + i];
+            if (!finite_t(x)) s_qbad = 1;
+            v = static_cast<double>(x);
+        }
+        qs[i] = v;
     }
 
-    using V = typename VecOf<TC>::type;
-    constexpr int VN = VecOf<TC>::N;
-    constexpr int VPR = DC / VN;                       // vectors per row per tile
-    constexpr int NV = (kRefRows * VPR) / kRefRows;    // vectors per lane per tile (= VPR)
-    V reg[NV];
-
-    auto issue = [&](int c0) {
-        if (VEC) {
+    // register double buffering: tile t+1 is in flight (global -> VGPR) while tile t is consumed from LDS
+    V reg[VPR];
+#define FSP_ISSUE(C0)                                                                                              \
+    if constexpr (VEC) {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                          \
+            const int v = tid + i * kRefRows;                                                                      \
+            const int row = v / VPR, cv = v - row * VPR;                                                           \
+            const int col = (C0) + cv * VN;                                                                        \
+            if (row < nrows && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(row) * d + col); \
+        }                                                                                                          \
+    }
+    double s = 0.0;
+    bool ok = true;
+    FSP_ISSUE(0)
+    for (int c0 = 0; c0 < d; c0 += DC) {
+        __syncthreads();  // previous tile fully consumed (and qs visible on the first pass)
+        if constexpr (VEC) {
 #pragma unroll
-            for (int i = 0; i < NV; i++) {
+            for (int i = 0; i < VPR; i++) {
                 const int v = tid + i * kRefRows;
                 const int row = v / VPR, cv = v - row * VPR;
                 const int col = c0 + cv * VN;
-                if (row < nrows && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(row) * d + col);
-            }
-        }
-    };
-    auto commit = [&](int c0) {
-        if (VEC) {
-#pragma unroll
-            for (int i = 0; i < NV; i++) {
-                const int v = tid + i * kRefRows;
-                const int row = v / VPR, cv = v - row * VPR;
-                const int col = c0 + cv * VN;
-                if (row < nrows && col < d) {
-                    const TC* e = reinterpret_cast<const TC*>(&reg[i]);
-#pragma unroll
-                    for (int x = 0; x < VN; x++) tile[(cv * VN + x) * LD + row] = e[x];
-                }
+                if (row < nrows && col < d) *reinterpret_cast<V*>(tile + row * PITCH + cv * VN) = reg[i];
             }
         } else {
             for (int e = tid; e < kRefRows * DC; e += kRefRows) {
                 const int row = e / DC, cc = e - row * DC;
-                if (row < nrows && c0 + cc < d) tile[cc * LD + row] = base[static_cast<int64_t>(row) * d + c0 + cc];
+                if (row < nrows && c0 + cc < d) tile[row * PITCH + cc] = base[static_cast<int64_t>(row) * d + c0 + cc];
             }
         }
-    };
-
-    double s = 0.0;
-    bool ok = true;
-    issue(0);
-    for (int c0 = 0; c0 < d; c0 += DC) {
-        __syncthreads();  // previous tile fully consumed (and qs visible on the first pass)
-        commit(c0);
-        if (c0 + DC < d) issue(c0 + DC);
+        if (c0 + DC < d) { FSP_ISSUE(c0 + DC) }
         __syncthreads();
         if (tid < nrows) {
             const int dc = min(DC, d - c0);
-#pragma unroll 8
-            for (int kk = 0; kk < dc; kk++) {
-                const TC x = tile[kk * LD + tid];
-                ok = ok && finite_t(x);
-                const double dd = qs[c0 + kk] - static_cast<double>(x);  // QSI.java:368
-                const double sq = dd * dd;
-                s = s + sq;                                              // QSI.java:369
+            const TC* myrow = tile + tid * PITCH;
+            if constexpr (VEC) {
+#pragma unroll 4
+                for (int kk = 0; kk < dc; kk += VN) {
+                    const V xv = *reinterpret_cast<const V*>(myrow + kk);
+#pragma unroll
+                    for (int e = 0; e < VN; e += 2) {
+                        const fsp_f64x2 qq = *reinterpret_cast<const fsp_f64x2*>(qs + c0 + kk + e);
+                        const double x0 = vcomp(xv, e), x1 = vcomp(xv, e + 1);   // exact widening
+                        ok = ok && (fabs(x0) <= 1.79769313486231570815e+308) && (fabs(x1) <= 1.79769313486231570815e+308);
+                        const double d0 = qq.x - x0;                             // QSI.java:368
+                        const double p0 = d0 * d0;
+                        s = s + p0;                                              // QSI.java:369 (in order)
+                        const double d1 = qq.y - x1;
+                        const double p1 = d1 * d1;
+                        s = s + p1;
+                    }
+                }
+            } else {
+                for (int kk = 0; kk < dc; kk++) {
+                    const TC x = myrow[kk];
+                    ok = ok && finite_t(x);
+                    const double dd = qs[c0 + kk] - static_cast<double>(x);
+                    const double sq = dd * dd;
+                    s = s + sq;
+                }
             }
         }
     }
+#undef FSP_ISSUE
     const bool qbad = (s_qbad != 0);
     const bool valid = (tid < nrows) && ok && !qbad;
     uint64_t key = kInvalidKey;
     if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
     keys[tid] = key;
-    if (valid) atomicAdd(&s_nvalid, 1);
+    {
+        const int c = __popcll(__ballot(valid));
+        if (lane == 0 && c) atomicAdd(&s_nvalid, c);
+    }
     __syncthreads();
     const int nvalid = s_nvalid;
-
-    // stable rank among the chunk's valid rows
-    int rank = 0;
-    if (valid) {
-        for (int j = 0; j < nrows; j++) {
-            const uint64_t kj = keys[j];
-            rank += (kj < key) || (kj == key && j < tid);
-        }
-    }
     const int eff = min(k, nvalid);
+
+    // ---- stable rank by (distance bits, candidate position) -------------------------------------
+    int rank = kRefRows;
+    if (k <= kRefFilterMaxK && nvalid > 2 * k) {
+        // per-wave k-th smallest key = upper bound of the chunk's k-th smallest; only keys <= the tightest
+        // bound (at most k per wave) are ranked against each other.
+        int lrank = 64;
+        if (valid) lrank = rank_among(keys + wave * 64, 64, key, lane);
+        const unsigned long long hit = __ballot(valid && lrank == k - 1);
+        if (lane == 0) s_wcut[wave] = kInvalidKey;
+        if (hit) {
+            const int src = __ffsll(static_cast<long long>(hit)) - 1;
+            if (lane == src) s_wcut[wave] = key;
+        }
+        __syncthreads();
+        uint64_t cutk = kInvalidKey;
+#pragma unroll
+        for (int w = 0; w < kRefRows / 64; w++) cutk = min(cutk, s_wcut[w]);
+        const bool sv = valid && key <= cutk;
+        // ordered compaction (keeps candidate order -> ties stay stable): wave prefix + per-wave base
+        const unsigned long long bm = __ballot(sv);
+        const int wcount = __popcll(bm);
+        __shared__ int s_wbase[kRefRows / 64];
+        if (lane == 0) s_wbase[wave] = wcount;
+        __syncthreads();
+        int basep = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kRefRows / 64; w++) {
+            if (w < wave) basep += s_wbase[w];
+            total += s_wbase[w];
+        }
+        const int mypos = basep + __popcll(bm & ((1ull << lane) - 1ull));
+        if (sv) surv[mypos] = key;
+        if (tid == 0 && (total & 1)) surv[total] = kInvalidKey;  // pad to an even count
+        __syncthreads();
+        if (sv) rank = rank_among(surv, (total + 1) & ~1, key, mypos);
+    } else if (valid) {
+        rank = rank_among(keys, kRefRows, key, tid);
+    }
+
     if (nchunks == 1) {
         if (valid && rank < eff) {
             out_ids[qi * k + rank] = cand_ids[qi * B + r0 + tid];
