@@ -1,0 +1,154 @@
+package com.fspann.gpu;
+
+import com.fspann.index.paper.Coding;
+import com.fspann.index.paper.GFunctionRegistry;
+import com.fspann.index.paper.GreedyPartitioner;
+
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.util.ArrayList;
+import java.util.BitSet;
+import java.util.HashMap;
+import java.util.List;
+import java.util.Map;
+
+/**
+ * Adapter the patched PartitionedIndexService / QueryTokenFactory / QueryServiceImpl delegate to
+ * (INTEGRATION.md §3 shows the three call sites).  It owns the String id <-> int handle map and the
+ * native context; AES-GCM, key versions and RocksDB stay exactly where they are in the reference.
+ *
+ * Not compiled in the build container (no JDK); it is the JVM twin of fspann-query-system_amd/operators.py,
+ * which IS exercised by the test-suite against the same C ABI.
+ */
+public final class GpuRouteRefine implements AutoCloseable {
+    private final long ctx;
+    private final int tables, divisions, m, lambda, dim, words;
+    private final List<String> idOf = new ArrayList<>();
+    private final Map<String, Integer> handleOf = new HashMap<>();
+
+    public GpuRouteRefine(int device, int tables, int divisions, int m, int lambda, int dim,
+                          int probeOverride, int maxGlobalCandidates, int refinementLimit, int hammingThreshold) {
+        this.tables = tables; this.divisions = divisions; this.m = m; this.lambda = lambda; this.dim = dim;
+        this.words = (m * lambda + 63) / 64;
+        this.ctx = FspannNative.ctxCreate(device, new int[]{tables, divisions, m, lambda, dim, 64, 5, probeOverride,
+                maxGlobalCandidates, refinementLimit, hammingThreshold});
+    }
+
+    private static ByteBuffer buf(long bytes) {
+        return ByteBuffer.allocateDirect((int) bytes).order(ByteOrder.nativeOrder());
+    }
+
+    /** Export GFunctionRegistry (idx/GFunctionRegistry.java:185-202) — the JVM's own alpha/r/omega, bit for bit. */
+    public void exportGFunctions() {
+        int TD = tables * divisions;
+        ByteBuffer a = buf(8L * TD * m * dim), r = buf(8L * TD * m), w = buf(8L * TD * m);
+        for (int t = 0; t < tables; t++)
+            for (int d = 0; d < divisions; d++) {
+                Coding.GFunction g = GFunctionRegistry.get(dim, t, d);
+                for (int j = 0; j < m; j++) {
+                    for (int i = 0; i < dim; i++) a.putDouble(g.alpha[j][i]);
+                    r.putDouble(g.r[j]);
+                    w.putDouble(g.omega[j]);
+                }
+            }
+        FspannNative.check(FspannNative.setGFunctions(ctx, a, r, w));
+    }
+
+    /** Export the frozen partitions of one (t,d) (DivisionState.partitions, PIS:111-113) after PIS.build. */
+    public void exportTable(int t, int d, List<GreedyPartitioner.Partition> parts) {
+        int n = parts.size();
+        long nIds = 0;
+        for (GreedyPartitioner.Partition p : parts) nIds += p.ids.size();
+        ByteBuffer mn = buf(8L * n), mx = buf(8L * n), rep = buf(8L * n * words), off = buf(8L * (n + 1)), ids = buf(4L * nIds);
+        long o = 0;
+        for (GreedyPartitioner.Partition p : parts) {
+            mn.putLong(p.minKey);
+            mx.putLong(p.maxKey);
+            long[] w = p.repCode.toLongArray();           // bit i -> word i/64, bit i%64
+            for (int k = 0; k < words; k++) rep.putLong(k < w.length ? w[k] : 0L);
+            off.putLong(o);
+            for (String id : p.ids) ids.putInt(handle(id));
+            o += p.ids.size();
+        }
+        off.putLong(o);
+        FspannNative.check(FspannNative.setIndex(ctx, t * divisions + d, n, mn, mx, rep, off, ids));
+    }
+
+    private int handle(String id) {
+        Integer h = handleOf.get(id);
+        if (h != null) return h;
+        int nh = idOf.size();
+        idOf.add(id);
+        handleOf.put(id, nh);
+        return nh;
+    }
+
+    /** After all tables are exported: String.hashCode per handle + metadata.isDeleted mirror, then freeze. */
+    public void finish(java.util.function.Predicate<String> isDeleted) {
+        int n = idOf.size();
+        ByteBuffer jh = buf(4L * n), del = buf(n);
+        for (String id : idOf) {
+            jh.putInt(id.hashCode());
+            del.put((byte) (isDeleted.test(id) ? 1 : 0));
+        }
+        FspannNative.check(FspannNative.setIdMeta(ctx, n, jh, del));
+        FspannNative.check(FspannNative.finalizeIndex(ctx));
+    }
+
+    /** QueryTokenFactory.create :98-131 — BitSet[tables][divisions] of one query vector. */
+    public BitSet[][] codes(double[] vec) {
+        ByteBuffer q = buf(8L * dim), c = buf(8L * tables * divisions * words);
+        for (double x : vec) q.putDouble(x);
+        FspannNative.check(FspannNative.encode(ctx, 1, q, FspannNative.F64, c, null));   // NaN/Inf -> IllegalArgumentException
+        BitSet[][] out = new BitSet[tables][divisions];
+        for (int t = 0; t < tables; t++)
+            for (int d = 0; d < divisions; d++) {
+                long[] w = new long[words];
+                for (int k = 0; k < words; k++) w[k] = c.getLong(8 * ((t * divisions + d) * words + k));
+                out[t][d] = BitSet.valueOf(w);
+            }
+        return out;
+    }
+
+    /** Result of Route for one query, in the reference's list order. */
+    public static final class Routed { public String[] ids; public long[] score; public int kept, rawSeen; }
+
+    /** PIS.lookupCandidatesWithScores (limit = Integer.MAX_VALUE) / QSI stage A.5 (limit = refinementLimit). */
+    public Routed route(BitSet[][] codes, int probeOverride, int limit) {
+        int TD = tables * divisions;
+        ByteBuffer c = buf(8L * TD * words);
+        for (int t = 0; t < tables; t++)
+            for (int d = 0; d < divisions; d++) {
+                long[] w = codes[t][d].toLongArray();
+                for (int k = 0; k < words; k++) c.putLong(k < w.length ? w[k] : 0L);
+            }
+        long cap = Math.min(limit, FspannNative.routeMaxCandidates(ctx, probeOverride));
+        ByteBuffer ids = buf(4 * cap), sc = buf(4 * cap), cnt = buf(4), kept = buf(4), raw = buf(4);
+        FspannNative.check(FspannNative.route(ctx, 1, c, probeOverride, limit, cap, ids, sc, cnt, kept, raw));
+        Routed r = new Routed();
+        int n = cnt.getInt(0);
+        r.ids = new String[n];
+        r.score = new long[n];
+        for (int i = 0; i < n; i++) { r.ids[i] = idOf.get(ids.getInt(4 * i)); r.score[i] = sc.getInt(4 * i); }
+        r.kept = kept.getInt(0);
+        r.rawSeen = raw.getInt(0);
+        return r;
+    }
+
+    /** QSI stage B distances + stage C: rows = decrypted candidate vectors in F_q order (skipped ones absent). */
+    public int[] refine(double[] q, double[][] rows, int k, double[] outDist) {
+        int B = Math.max(1, rows.length);
+        ByteBuffer qb = buf(8L * dim), cb = buf(8L * B * dim), ib = buf(4L * B), nb = buf(4);
+        for (double x : q) qb.putDouble(x);
+        for (int j = 0; j < rows.length; j++) { for (double x : rows[j]) cb.putDouble(x); ib.putInt(j); }
+        nb.putInt(rows.length);
+        ByteBuffer oi = buf(4L * k), od = buf(8L * k), oc = buf(4), sc = buf(4);
+        FspannNative.check(FspannNative.refine(ctx, 1, qb, cb, FspannNative.F64, B, ib, nb, k, oi, od, oc, sc));
+        int eff = oc.getInt(0);
+        int[] order = new int[eff];
+        for (int i = 0; i < eff; i++) { order[i] = oi.getInt(4 * i); outDist[i] = od.getDouble(8 * i); }
+        return order;   // indices into `rows`
+    }
+
+    @Override public void close() { FspannNative.ctxDestroy(ctx); }
+}
