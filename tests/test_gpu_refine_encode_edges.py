@@ -1,0 +1,169 @@
+"""GPU parity, Refine and Encode edge cases against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(pkg, d, B=64, T=1, D=1, m=8, lam=2):
+    return pkg.FspannContext(pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=lam, dim=d, refinement_limit=B), 0)
+
+
+def _check_refine(pkg, oracle, q, cand, ids, cnt, k, dtype=np.float32):
+    q = q.astype(dtype)
+    cand = cand.astype(dtype)
+    ref_ids, ref_dist, ref_cnt = oracle.refine(q.astype(np.float64), cand.astype(np.float64), ids, cnt, k)
+    with _ctx(pkg, cand.shape[2], B=cand.shape[1]) as ctx:
+        res = ctx.refine(q, cand, ids, cnt, k)
+    assert np.array_equal(res["count"], ref_cnt)
+    assert np.array_equal(res["ids"], ref_ids)
+    assert np.array_equal(res["dist"], ref_dist)
+    return res
+
+
+@pytest.mark.parametrize("B,k,d", [(256, 10, 128), (256, 1, 128), (256, 100, 64), (300, 10, 32), (1000, 50, 16),
+                                   (6000, 100, 24), (64, 10, 960), (17, 32, 7), (257, 33, 12)])
+def test_refine_shapes(pkg, oracle, B, k, d):
+    rng = np.random.default_rng(B * 31 + k)
+    nq = 5
+    q = rng.standard_normal((nq, d))
+    cand = rng.standard_normal((nq, B, d))
+    ids = rng.integers(0, 10**6, (nq, B)).astype(np.int32)
+    cnt = np.array([B, 0, 1, min(B, k - 1) if k > 1 else 1, B // 2], np.int32)
+    for dt in (np.float32, np.float64):
+        _check_refine(pkg, oracle, q, cand, ids, cnt, k, dt)
+
+
+def test_refine_ties_are_stable(pkg, oracle):
+    """Equal distances keep candidate order (List.sort is stable, QSI:298)."""
+    rng = np.random.default_rng(1)
+    nq, B, d, k = 3, 512, 16, 20
+    base = rng.standard_normal((nq, 8, d))
+    cand = base[:, rng.integers(0, 8, B)][np.arange(nq)[:, None], np.arange(B)[None] % 1 + np.zeros((nq, B), int)]
+    cand = np.stack([base[i][rng.integers(0, 8, B)] for i in range(nq)])      # only 8 distinct rows per query
+    q = rng.standard_normal((nq, d))
+    ids = np.tile(np.arange(B, dtype=np.int32), (nq, 1))
+    cnt = np.full(nq, B, np.int32)
+    res = _check_refine(pkg, oracle, q, cand, ids, cnt, k)
+    for i in range(nq):
+        dist = res["dist"][i]
+        same = np.flatnonzero(np.diff(dist) == 0)
+        assert len(same) > 0
+        assert all(res["ids"][i][j] < res["ids"][i][j + 1] for j in same)      # ties in ascending position
+
+
+def test_refine_nonfinite(pkg, oracle):
+    rng = np.random.default_rng(2)
+    nq, B, d, k = 4, 256, 32, 10
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    cand = rng.standard_normal((nq, B, d)).astype(np.float32)
+    cand[0, 3, 5] = np.nan          # candidate skipped (QSI:253-260)
+    cand[0, 7, 0] = np.inf
+    cand[1, :, 2] = -np.inf         # every candidate invalid -> empty result
+    q[2, 4] = np.nan                # invalid query -> empty result (QSI:137-140)
+    cand[3, 9, :] = 3.0e38          # finite inputs, squared sum stays finite in fp64 -> kept
+    ids = np.tile(np.arange(B, dtype=np.int32), (nq, 1))
+    cnt = np.full(nq, B, np.int32)
+    ref_ids, ref_dist, ref_cnt = oracle.refine(q.astype(np.float64), cand.astype(np.float64), ids, cnt, k)
+    ref_cnt[2] = 0                  # the oracle helper does not model the query check; QSI returns empty
+    ref_ids[2] = -1
+    ref_dist[2] = np.inf
+    with _ctx(pkg, d, B) as ctx:
+        res = ctx.refine(q, cand, ids, cnt, k)
+    assert np.array_equal(res["count"], ref_cnt) and list(res["count"]) == [10, 0, 0, 10]
+    assert np.array_equal(res["ids"], ref_ids)
+    assert np.array_equal(res["dist"], ref_dist)
+    assert list(res["scored"]) == [B - 2, 0, 0, B]
+
+
+def test_refine_sqrt_is_correctly_rounded(pkg):
+    """Math.sqrt is IEEE-exact; check the device sqrt on awkward arguments through d = 1 distances."""
+    rng = np.random.default_rng(3)
+    B = 256
+    vals = np.concatenate([rng.random(100) * 1e-300, rng.random(100) * 1e300, [0.0, 1.0, 2.0, 3.0, 1e-320, 4.9e-324],
+                           rng.random(50)]).astype(np.float64)[:B]
+    cand = np.sqrt(vals).reshape(1, B, 1)             # distance = |0 - x| = sqrt(x^2) ...
+    q = np.zeros((1, 1))
+    with _ctx(pkg, 1, B) as ctx:
+        res = ctx.refine(q, cand, np.arange(B, dtype=np.int32)[None], np.array([B], np.int32), B)
+    got = dict(zip(res["ids"][0], res["dist"][0]))
+    for j in range(B):
+        x = cand[0, j, 0]
+        assert got[j] == np.sqrt(x * x)
+
+
+@pytest.mark.parametrize("T,D,m,lam,d", [(1, 1, 1, 1, 1), (3, 2, 24, 2, 128), (2, 3, 7, 5, 300), (10, 20, 16, 2, 16),
+                                         (2, 2, 100, 3, 33), (1, 2, 256, 2, 8), (2, 1, 16, 32, 12)])
+def test_encode_shapes(pkg, oracle, T, D, m, lam, d):
+    rng = np.random.default_rng(T * 100 + m)
+    S = rng.standard_normal((200, d))
+    alpha, r, w = oracle.registry_init(S, m, 7, T, D)
+    o = oracle.Oracle(T, D, m, lam, d)
+    o.set_gfunctions(alpha, r, w)
+    Q = (rng.standard_normal((19, d)) * 4).astype(np.float32)
+    with _ctx(pkg, d, T=T, D=D, m=m, lam=lam) as ctx:
+        ctx.set_gfunctions(alpha, r, w)
+        codes, hs = ctx.encode(Q, want_hashes=True)
+        codes64 = ctx.encode(Q.astype(np.float64))
+    assert np.array_equal(hs, o.hashes(Q.astype(np.float64)))
+    assert np.array_equal(codes, o.encode(Q.astype(np.float64)))
+    assert np.array_equal(codes64, codes)
+
+
+def test_encode_saturation_and_negative_hashes(pkg, oracle):
+    T, D, m, lam, d = 1, 2, 12, 4, 6
+    rng = np.random.default_rng(5)
+    alpha, r, w = oracle.registry_init(rng.standard_normal((50, d)) * 1e-3, m, 3, T, D)   # tiny omega
+    o = oracle.Oracle(T, D, m, lam, d)
+    o.set_gfunctions(alpha, r, w)
+    Q = np.stack([np.full(d, 1e300), np.full(d, -1e300), np.full(d, 1e12), -np.arange(d) * 7.0, np.zeros(d),
+                  np.full(d, 2147483647.0 * w.max()), rng.standard_normal(d) * 1e6])
+    H = o.hashes(Q)
+    assert (H == 2**31 - 1).any() and (H == -2**31).any() and (H < 0).any()               # (int) cast saturates
+    with _ctx(pkg, d, T=T, D=D, m=m, lam=lam) as ctx:
+        ctx.set_gfunctions(alpha, r, w)
+        codes, hs = ctx.encode(Q, want_hashes=True)
+    assert np.array_equal(hs, H)
+    assert np.array_equal(codes, o.encode(Q))
+
+
+def test_encode_rejects_nan_inf(pkg, oracle):
+    T, D, m, lam, d = 2, 1, 8, 2, 10
+    alpha, r, w = oracle.registry_init(np.random.default_rng(6).standard_normal((50, d)), m, 3, T, D)
+    with _ctx(pkg, d, T=T, D=D, m=m, lam=lam) as ctx:
+        with pytest.raises(pkg.FspannStateError):       # GFunctionRegistry not initialized
+            ctx.encode(np.zeros((1, d)))
+        ctx.set_gfunctions(alpha, r, w)
+        Q = np.zeros((5, d))
+        Q[3, 2] = np.nan
+        with pytest.raises(pkg.FspannArgumentError, match="NaN/Inf"):
+            ctx.encode(Q)
+        Q[3, 2] = -np.inf
+        with pytest.raises(ValueError):
+            ctx.encode(Q.astype(np.float32))
+        with pytest.raises(pkg.FspannArgumentError):
+            ctx.encode(np.zeros(d + 1))
+
+
+def test_encode_bulk_path(pkg, oracle):
+    """nq >= 8192 takes the 8-queries-per-block variant (index coding)."""
+    T, D, m, lam, d = 2, 2, 16, 2, 24
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((9000, d)).astype(np.float32)
+    alpha, r, w = oracle.registry_init(X[:500].astype(np.float64), m, 13, T, D)
+    o = oracle.Oracle(T, D, m, lam, d)
+    o.set_gfunctions(alpha, r, w)
+    with _ctx(pkg, d, T=T, D=D, m=m, lam=lam) as ctx:
+        ctx.set_gfunctions(alpha, r, w)
+        assert np.array_equal(ctx.encode(X), o.encode(X.astype(np.float64)))
+
+
+def test_native_registry_initialize_matches_oracle(pkg, oracle):
+    T, D, m, lam, d = 3, 2, 10, 2, 20
+    S = np.random.default_rng(9).standard_normal((1000, d)).astype(np.float32).astype(np.float64)
+    a0, r0, w0 = oracle.registry_init(S, m, 13, T, D)
+    with _ctx(pkg, d, T=T, D=D, m=m, lam=lam) as ctx:
+        ctx.registry_initialize(S, 13)
+        a, r, w = ctx.get_gfunctions()
+    assert np.array_equal(w, w0) and np.array_equal(r, r0)      # exact fp64 projections on the GPU
+    assert np.array_equal(a, a0)                                # same libm on this box; else compare to 1e-15
