@@ -103,6 +103,8 @@ _SIGS = {
     "fspann_get_index": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fspann_encode": (_i, [_vp, _i64, _vp, _i, _vp, _vp]),
     "fspann_encode_dev": (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp]),
+    "fspann_set_encode_mode": (_i, [_vp, _i]),
+    "fspann_last_encode_rechecked": (_i64, [_vp]),
     "fspann_route": (_i, [_vp, _i64, _vp, _i, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fspann_route_dev": (_i, [_vp, _i64, _vp, _i, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fspann_route_max_candidates": (_i64, [_vp, _i]),

@@ -32,7 +32,9 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
     const TIn* __restrict__ q, int64_t nq, int d, const double* __restrict__ alphaT,
     const double* __restrict__ r, const double* __restrict__ omega, int P, int m, int lambda, int W, int TD,
     int tdPerBlock, uint64_t* __restrict__ codes, int32_t* __restrict__ hashes, int32_t* __restrict__ bad,
-    double* __restrict__ proj) {
+    double* __restrict__ proj, const unsigned long long* __restrict__ only_if_over, unsigned long long over_cap) {
+    // fallback launch behind the MFMA path: runs only when its re-check list overflowed
+    if (only_if_over && *only_if_over <= over_cap) return;
     __shared__ double vs[QB * kEncDC];
     __shared__ int32_t Hs[QB * kEncThreads];
     __shared__ int badq[QB];
@@ -115,6 +117,162 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
         codes[(qi * TD + td0 + tdl) * W + w] = word;
     }
     if (bad && blockIdx.y == 0 && tid < QB && q0 + tid < nq) bad[q0 + tid] = badq[tid];
+}
+
+}  // namespace fspann
+
+// =====================================================================================
+// MFMA fast path (SURVEY §7 hard part 1, plan (b)): y32 = V · A^T as an exact-f32 MFMA GEMM
+// (v_mfma_f32_32x32x2_f32), then h = floor((y + r)/omega) is accepted only when y is provably
+// on the same side of every bucket boundary as the reference's fp64 sum; the remaining
+// (query, projection) pairs are recomputed by encode_fix_kernel with the exact fp64 chain.
+// Results are therefore bit-identical to encode_exact_kernel by construction.
+//
+// Error bound: |y32 - y_ref| <= (d + 4) * 2^-24 * sum_i |v_i alpha_i| <= (d + 4) * 2^-24 * ||v||_2
+// (alpha rows are L2-normalised, idx/Coding.java:149-150; the factor covers the f32 rounding of alpha
+// and of an fp64 input, the k-ordered f32 fma chain and the f32 product roundings), inflated by 1.01.
+// =====================================================================================
+#pragma clang fp contract(off)
+namespace fspann {
+
+typedef float fsp_acc16 __attribute__((ext_vector_type(16)));
+constexpr int kMfmaKT = 32;       // K tile
+constexpr int kMfmaTile = 64;     // block tile: 64 queries x 64 projections, 4 waves as 2 x 2
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void encode_mfma_kernel(
+    const TIn* __restrict__ q, int64_t nq, int d, const float* __restrict__ alphaT32 /*[d][P]*/,
+    const double* __restrict__ r, const double* __restrict__ omega, int P, int32_t* __restrict__ hashes,
+    int32_t* __restrict__ bad, int64_t* __restrict__ fix_list, int64_t fix_cap, unsigned long long* __restrict__ fix_count,
+    double alpha_norm_max) {
+    __shared__ float Vs[kMfmaTile][kMfmaKT + 1];
+    __shared__ float As[kMfmaKT][kMfmaTile];
+    __shared__ double rnorm2[kMfmaTile];
+    __shared__ int badrow[kMfmaTile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t q0 = static_cast<int64_t>(blockIdx.x) * kMfmaTile;
+    const int p0 = blockIdx.y * kMfmaTile;
+    if (tid < kMfmaTile) { rnorm2[tid] = 0.0; badrow[tid] = 0; }
+    fsp_acc16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    double nrm[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) nrm[i] = 0.0;
+    __syncthreads();
+
+    for (int k0 = 0; k0 < d; k0 += kMfmaKT) {
+        // V tile: 64 rows x 32 k; thread t covers column t&31 of rows (t>>5) + 8 i
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int row = (tid >> 5) + 8 * i, col = tid & 31;
+            const int64_t qi = q0 + row;
+            double v = 0.0;
+            if (qi < nq && k0 + col < d) {
+                v = static_cast<double>(q[qi * d + k0 + col]);
+                if (!(fabs(v) <= 1.79769313486231570815e+308)) badrow[row] = 1;
+            }
+            Vs[row][col] = static_cast<float>(v);
+            nrm[i] += v * v;
+        }
+        // A tile: 32 k x 64 projections (coalesced rows of alphaT32)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int e = tid + i * 256;
+            const int kk = e >> 6, pc = e & 63;
+            float a = 0.0f;
+            if (k0 + kk < d && p0 + pc < P) a = alphaT32[static_cast<int64_t>(k0 + kk) * P + p0 + pc];
+            As[kk][pc] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kMfmaKT; kk += 2) {
+            const float a = Vs[wm * 32 + (lane & 31)][kk + (lane >> 5)];
+            const float b = As[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // row norms: reduce the 32 lanes that share a row, one writer per row
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        double s = nrm[i];
+        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if ((tid & 31) == 0) rnorm2[(tid >> 5) + 8 * i] = s;
+    }
+    __syncthreads();
+    if (bad && blockIdx.y == 0 && tid < kMfmaTile && q0 + tid < nq) bad[q0 + tid] = badrow[tid];
+
+    // per-row guard band (y units): gamma * ||v||_2 + f32-underflow floor
+    const double gamma = 1.01 * static_cast<double>(d + 4) * 5.9604644775390625e-08 * alpha_norm_max;  // 2^-24
+    if (tid < kMfmaTile) rnorm2[tid] = gamma * sqrt(rnorm2[tid]) * 1.0000001 + static_cast<double>(d) * 1.2e-38;
+    __syncthreads();
+    const int col = wn * 32 + (lane & 31);
+    const int p = p0 + col;
+    const double rr = (p < P) ? r[p] : 0.0, ww = (p < P) ? omega[p] : 1.0;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int row = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int64_t qi = q0 + row;
+        if (qi >= nq || p >= P) continue;
+        const double y = static_cast<double>(acc[reg]);
+        const double band = rnorm2[row];
+        const double fl = floor((y + rr) / ww);
+        // bucket edges in y units; safe iff [y - band, y + band] lies strictly inside (edge_lo, edge_hi)
+        // with a margin for the fp64 roundings of the edges and of the reference's own (y + r)/omega
+        const double e_lo = fl * ww - rr, e_hi = (fl + 1.0) * ww - rr;
+        const double mg = 8.9e-16 * (fabs(fl * ww) + fabs(ww) + fabs(rr) + fabs(y));
+        const bool safe = (y - band > e_lo + mg) && (y + band < e_hi - mg) && (fabs(fl) < 2147483000.0) && !badrow[row];
+        hashes[qi * P + p] = java_d2i(fl);
+        if (!safe) {
+            const unsigned long long pos = atomicAdd(fix_count, 1ull);
+            if (pos < static_cast<unsigned long long>(fix_cap)) fix_list[pos] = qi * P + p;
+        }
+    }
+}
+
+// exact re-computation of the flagged (query, projection) pairs: one lane per pair, the reference's chain.
+template <typename TIn>
+__global__ __launch_bounds__(256) void encode_fix_kernel(const TIn* __restrict__ q, int d, const double* __restrict__ alphaT,
+                                                         const double* __restrict__ r, const double* __restrict__ omega, int P,
+                                                         const int64_t* __restrict__ fix_list, const unsigned long long* __restrict__ fix_count,
+                                                         int64_t fix_cap, int32_t* __restrict__ hashes) {
+    const unsigned long long n = min(*fix_count, static_cast<unsigned long long>(fix_cap));
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+        const int64_t e = fix_list[i];
+        const int64_t qi = e / P;
+        const int p = static_cast<int>(e - qi * P);
+        const TIn* v = q + qi * d;
+        double acc = 0.0;
+        for (int k = 0; k < d; k++) {
+            const double prod = static_cast<double>(v[k]) * alphaT[static_cast<int64_t>(k) * P + p];
+            acc = acc + prod;
+        }
+        const double y = acc + r[p];
+        hashes[e] = java_d2i(floor(y / omega[p]));
+    }
+}
+
+// Coding.C from the int32 hashes: one thread per code word.
+__global__ __launch_bounds__(256) void encode_pack_kernel(const int32_t* __restrict__ hashes, int64_t nq, int TD, int m, int lambda,
+                                                          int W, uint64_t* __restrict__ codes) {
+    const int64_t wi = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (wi >= nq * TD * W) return;
+    const int64_t qt = wi / W;
+    const int w = static_cast<int>(wi - qt * W);
+    const int32_t* H = hashes + qt * m;
+    const int bitsTotal = m * lambda;
+    uint64_t word = 0;
+    const int pos0 = w * 64, pos1 = min(bitsTotal, pos0 + 64);
+    int plane = pos0 / m, j = pos0 - plane * m;
+    for (int pos = pos0; pos < pos1; pos++) {
+        const uint32_t hj = static_cast<uint32_t>(H[j]) ^ 0x80000000u;
+        word |= static_cast<uint64_t>((hj >> ((lambda - 1 - plane) & 31)) & 1u) << (pos - pos0);
+        if (++j == m) { j = 0; plane++; }
+    }
+    codes[wi] = word;
 }
 
 }  // namespace fspann

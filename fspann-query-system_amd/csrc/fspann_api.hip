@@ -95,25 +95,65 @@ int upload_index(fspann_ctx* c) {
 }
 
 template <typename TIn>
+int launch_encode_mfma(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_dev, int32_t* hashes_dev, int32_t* bad_dev) {
+    const int P = c->P_total, d = c->cfg.dim;
+    const int64_t cap = std::max<int64_t>(65536, nq * P / 16);
+    const size_t hb = hashes_dev ? 0 : static_cast<size_t>(nq) * P * 4;
+    int rc = ensure(c, c->ws_fix, 256 + static_cast<size_t>(cap) * 8 + hb);
+    if (rc) return rc;
+    unsigned long long* cnt = static_cast<unsigned long long*>(c->ws_fix.p);
+    int64_t* list = reinterpret_cast<int64_t*>(static_cast<char*>(c->ws_fix.p) + 256);
+    int32_t* H = hashes_dev ? hashes_dev : reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_fix.p) + 256 + static_cast<size_t>(cap) * 8);
+    FSP_HIP(hipMemsetAsync(cnt, 0, 8, c->stream));
+    dim3 grid(static_cast<unsigned>((nq + kMfmaTile - 1) / kMfmaTile), static_cast<unsigned>((P + kMfmaTile - 1) / kMfmaTile));
+    hipLaunchKernelGGL((encode_mfma_kernel<TIn>), grid, dim3(256), 0, c->stream, q_dev, nq, d, c->d_alphaT32, c->d_r, c->d_omega, P, H,
+                       bad_dev, list, cap, cnt, c->alpha_norm_max);
+    FSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL((encode_fix_kernel<TIn>), dim3(static_cast<unsigned>(std::min<int64_t>(1024, (cap + 255) / 256))), dim3(256), 0, c->stream,
+                       q_dev, d, c->d_alphaT, c->d_r, c->d_omega, P, list, cnt, cap, H);
+    FSP_HIP(hipGetLastError());
+    const int64_t nwords = nq * c->TD * c->W;
+    hipLaunchKernelGGL(encode_pack_kernel, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, c->stream, H, nq, c->TD,
+                       c->cfg.m, c->cfg.lambda, c->W, codes_dev);
+    FSP_HIP(hipGetLastError());
+    c->fix_cap_last = static_cast<unsigned long long>(cap);
+    return 1;  // caller enqueues the exact kernel guarded by (count > cap): it only runs if the list overflowed
+}
+
+template <typename TIn>
 int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_dev, int32_t* hashes_dev,
                   int32_t* bad_dev, double* proj_dev = nullptr) {
     const int m = c->cfg.m;
+    const unsigned long long* guard = nullptr;
+    unsigned long long guard_cap = 0;
+    const bool want_mfma = (c->encode_mode == 2) || (c->encode_mode == 0 && nq >= 4096);
+    if (want_mfma && !proj_dev && c->d_alphaT32) {
+        int rc = launch_encode_mfma<TIn>(c, nq, q_dev, codes_dev, hashes_dev, bad_dev);
+        if (rc <= 0) return rc;  // error
+        // the list can only overflow when almost every pair sits on a bucket boundary (degenerate omega): the
+        // exact kernel below is enqueued with a device-side guard and returns immediately otherwise.
+        guard = static_cast<const unsigned long long*>(c->ws_fix.p);
+        guard_cap = c->fix_cap_last;
+        c->mfma_last = true;
+    } else {
+        c->mfma_last = false;
+    }
     const int tdPerBlock = std::max(1, kEncThreads / m);
     const int gy = (c->TD + tdPerBlock - 1) / tdPerBlock;
-    // QB queries per block: 8 for bulk coding (index build), 4 for query batches so that
+    // QB queries per block: 8 for bulk coding (index build), 2 for query batches so that
     // a 1024-query batch still fills 256 CUs.
     if (nq >= 8192) {
         constexpr int QB = 8;
         dim3 grid(static_cast<unsigned>((nq + QB - 1) / QB), gy);
         hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), grid, dim3(kEncThreads), 0, c->stream, q_dev, nq,
                            c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD,
-                           tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev);
+                           tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap);
     } else {
         constexpr int QB = 2;
         dim3 grid(static_cast<unsigned>((nq + QB - 1) / QB), gy);
         hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), grid, dim3(kEncThreads), 0, c->stream, q_dev, nq,
                            c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD,
-                           tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev);
+                           tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap);
     }
     FSP_HIP(hipGetLastError());
     return FSPANN_OK;
@@ -298,7 +338,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega);
+    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_dev(c->ws_fix.p);
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
     free_dev(c->d_store);
@@ -325,7 +365,20 @@ int fspann_set_gfunctions(fspann_ctx* c, const double* alpha, const double* r, c
     std::vector<double> aT(static_cast<size_t>(d) * P);
     for (int p = 0; p < P; p++)
         for (int i = 0; i < d; i++) aT[static_cast<size_t>(i) * P + p] = alpha[static_cast<size_t>(p) * d + i];
-    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega);
+    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32);
+    {
+        std::vector<float> aT32(aT.size());
+        for (size_t i = 0; i < aT.size(); i++) aT32[i] = static_cast<float>(aT[i]);
+        double nmax = 0.0;
+        for (int pp = 0; pp < P; pp++) {
+            double s2 = 0.0;
+            for (int i = 0; i < d; i++) s2 += alpha[static_cast<size_t>(pp) * d + i] * alpha[static_cast<size_t>(pp) * d + i];
+            nmax = std::max(nmax, std::sqrt(s2));
+        }
+        c->alpha_norm_max = nmax * (1.0 + 1e-12);
+        FSP_HIP(hipMalloc(&c->d_alphaT32, aT32.size() * 4));
+        FSP_HIP(hipMemcpy(c->d_alphaT32, aT32.data(), aT32.size() * 4, hipMemcpyHostToDevice));
+    }
     FSP_HIP(hipMalloc(&c->d_alphaT, aT.size() * 8));
     FSP_HIP(hipMalloc(&c->d_r, static_cast<size_t>(P) * 8));
     FSP_HIP(hipMalloc(&c->d_omega, static_cast<size_t>(P) * 8));
@@ -753,6 +806,24 @@ int fspann_store_gather_dev(fspann_ctx* c, int64_t nq, const int32_t* sel_ids_de
     }
     FSP_HIP(hipGetLastError());
     return FSPANN_OK;
+}
+
+// Encode path selection: 0 = auto (MFMA pre-filter for nq >= 4096, exact fp64 otherwise), 1 = exact fp64 VALU only,
+// 2 = always MFMA fp32 GEMM + exact re-check.  All modes produce bit-identical hashes and codes.
+int fspann_set_encode_mode(fspann_ctx* c, int mode) {
+    if (!c) return fail(FSPANN_E_NULL, "ctx is null");
+    if (mode < 0 || mode > 2) return fail(FSPANN_E_ARG, "encode mode must be 0, 1 or 2");
+    c->encode_mode = mode;
+    return FSPANN_OK;
+}
+// (query, projection) pairs the last MFMA-path encode re-checked with the exact kernel (0 for the exact path).
+int64_t fspann_last_encode_rechecked(fspann_ctx* c) {
+    if (!c) return FSPANN_E_NULL;
+    if (!c->mfma_last || !c->ws_fix.p) return 0;
+    unsigned long long n = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(&n, c->ws_fix.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return FSPANN_E_DEVICE;
+    return static_cast<int64_t>(n);
 }
 
 // debug: per-block phase stamps of the route kernel (dev pointer to [grid][8] int64, or NULL)

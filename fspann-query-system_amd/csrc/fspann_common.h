@@ -83,6 +83,12 @@ struct fspann_ctx {
     double* d_r = nullptr;
     double* d_omega = nullptr;
     std::vector<double> h_alpha, h_r, h_omega;  // host copies (export)
+    float* d_alphaT32 = nullptr;               // fp32 copy of alphaT for the MFMA fast path
+    double alpha_norm_max = 1.0;               // max_j ||alpha_j||_2 (error bound of the fast path)
+    int encode_mode = 0;                       // 0 auto, 1 exact fp64, 2 MFMA fp32 + exact re-check
+    unsigned long long fix_cap_last = 0;       // capacity of the re-check list of the last MFMA-path call
+    bool mfma_last = false;                    // the last encode took the MFMA path
+    fspann::DevBuf ws_fix;                     // fix list + counter + int32 hashes of the MFMA path
 
     // frozen index (concatenated over td)
     std::vector<fspann::RouteTable> h_tables;

@@ -385,12 +385,15 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
                     if (step < nprobe[td] && pos < pr.w) idv[u] = prm.ids[ids_base[td] + pr.z + pos];
                 }
             }
+            uint32_t slot0[8], first[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int j = j0 + u * nthreads;
-                if (j >= prm.max_tuples) continue;
+                slot0[u] = 0;
+                if (j >= prm.max_tuples) { idv[u] = -1; continue; }
                 int32_t id = idv[u];
                 if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1;
+                idv[u] = id;
                 const int ts = FSP_TS(j);
                 const int sc = probe[ts].y;
                 tup[j] = id;  // written before the CAS below publishes j (same wave: LDS ops stay in order)
@@ -403,23 +406,34 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
                     atomicAdd(&bins[sc], 1);
                     atomicAdd(&stepcnt[ts], 1);
                 }
-                if (id < 0) continue;
-                uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
+                if (id >= 0) slot0[u] = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
+            }
+            // optimistic first probe of all 8 tuples: independent CAS ops overlap their LDS round trips
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                first[u] = kHtEmpty;
+                if (idv[u] >= 0) first[u] = atomicCAS(&ht[slot0[u]], kHtEmpty, static_cast<uint32_t>(j0 + u * nthreads));
+            }
+            // the (fewer) tuples whose home slot was taken continue their probe sequence
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (idv[u] < 0 || first[u] == kHtEmpty) continue;   // created at the home slot
+                const int32_t id = idv[u];
+                const uint32_t j = static_cast<uint32_t>(j0 + u * nthreads);
+                uint32_t slot = slot0[u];
+                uint32_t cur = first[u];
                 const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> prm.ht_shift) | 1u;
                 while (true) {
-                    uint32_t cur = ht[slot];
-                    if (cur == kHtEmpty) {
-                        cur = atomicCAS(&ht[slot], kHtEmpty, static_cast<uint32_t>(j));
-                        if (cur == kHtEmpty) break;  // created
-                    }
                     if (tup[cur] == id) {            // same id (whichever occurrence currently sits there)
-                        const uint32_t old = atomicMin(&ht[slot], static_cast<uint32_t>(j));
-                        const uint32_t loser = max(old, static_cast<uint32_t>(j));  // exactly one repeat per meeting
+                        const uint32_t old = atomicMin(&ht[slot], j);
+                        const uint32_t loser = max(old, j);  // exactly one repeat per meeting
                         const int pos = atomicAdd(&s_ndup, 1);
                         if (pos < kDupListMax) duplist[pos] = static_cast<int32_t>(loser);
                         break;
                     }
                     slot = (slot + stp) & ht_mask;
+                    cur = atomicCAS(&ht[slot], kHtEmpty, j);
+                    if (cur == kHtEmpty) break;      // created
                 }
             }
         }

@@ -166,6 +166,13 @@ class FspannContext:
         N.check(self.L.fspann_encode(self._h, nq, _p(q), _dt(q), _p(codes), _p(hs)))
         return (codes, hs) if want_hashes else codes
 
+    def set_encode_mode(self, mode: int):
+        """0 auto, 1 exact fp64, 2 MFMA fp32 + exact re-check (all bit-identical)."""
+        N.check(self.L.fspann_set_encode_mode(self._h, mode))
+
+    def last_encode_rechecked(self) -> int:
+        return int(self.L.fspann_last_encode_rechecked(self._h))
+
     # -- Route ---------------------------------------------------------------------
     def effective_probes(self, probe_override=-1):
         return self.L.fspann_effective_probes(self._h, probe_override)

@@ -126,6 +126,12 @@ int fspann_encode(fspann_ctx* ctx, int64_t nq, const void* q, int dtype, uint64_
 int fspann_encode_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int dtype, uint64_t* codes_dev,
                       int32_t* hashes_dev, int32_t* bad_dev /* [nq], 1 where NaN/Inf */);
 
+/* Encode path: 0 = auto (MFMA fp32 GEMM pre-filter + exact fp64 re-check for nq >= 4096, exact fp64 VALU kernel
+ * otherwise), 1 = exact only, 2 = always MFMA + re-check.  Every mode returns bit-identical hashes/codes: an
+ * MFMA result is kept only when its error interval lies strictly inside one bucket of floor((y+r)/omega).    */
+int fspann_set_encode_mode(fspann_ctx* ctx, int mode);
+int64_t fspann_last_encode_rechecked(fspann_ctx* ctx);
+
 /* ---- Route: PIS.lookupCandidatesWithScores (PIS:592-715) ---------------------------
  * codes = [nq][T*D][W].  probe_override > 0 overrides like PIS.setProbeOverride (PIS:868,
  * 880-888).  Writes, per query, the first min(limit, kept) entries of the reference's result
