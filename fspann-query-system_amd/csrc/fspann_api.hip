@@ -638,12 +638,14 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     p.java_hash = c->d_java_hash; p.deleted_bits = c->d_deleted_bits;
     p.nq = nq; p.TD = c->TD; p.W = c->W; p.P = pl.P; p.S = pl.S; p.S_shift = pl.S_shift;
     p.hard_cap = c->hard_cap; p.cap0 = c->cap0; p.limit = limit; p.need_cap = pl.need_cap; p.nbins = pl.nbins;
+    p.seq_bits = 1; while ((1 << p.seq_bits) < pl.max_tuples) p.seq_bits++;
     p.ht_size = pl.ht_size; p.ht_shift = pl.ht_shift; p.sort_cap = pl.sort_cap; p.max_tuples = pl.max_tuples;
     p.g_sort = so_g ? static_cast<uint64_t*>(c->ws_route.p) : nullptr;
     p.g_sort_stride = pl.g_sort_stride;
     p.g_scratch = ar_g ? static_cast<unsigned char*>(c->ws_route.p) + ((so_g + 255) & ~size_t(255)) : nullptr;
     p.g_stride = static_cast<int64_t>(pl.arena_bytes);
     p.dbg = c->dbg_route;
+    { const char* e = getenv("FSPANN_ROUTE_DBG_SKIP"); p.dbg_skip = e ? atoi(e) : 0; }
     p.decimal_ids = c->decimal_ids ? 1 : 0;
     p.out_cap = cap; p.out_ids = ids_dev; p.out_score = score_dev; p.out_count = count_dev; p.out_kept = kept_dev; p.out_raw = raw_seen_dev;
     // kernel 1: search + probe order, one lane group per (query, table)

@@ -52,6 +52,7 @@ struct RouteParams {
     int need_cap;                  // 1 if TD*P*S >= hard_cap (the cap can trigger)
     int nbins;                     // bits + 1 score bins (<= 1024)
     int ht_size, ht_shift;         // power of two; shift = 32 - log2
+    int seq_bits;                  // ceil(log2(max_tuples)): hash entries are (tag << seq_bits) | seq
     int sort_cap;                  // entries of the per-block sort buffer (LDS or global)
     int max_tuples;                // TD*P*S
     unsigned char* g_scratch;      // global fallback arena (per block g_stride bytes) when !kLds
@@ -65,6 +66,7 @@ struct RouteParams {
     int32_t* out_kept;
     int32_t* out_raw;
     int decimal_ids;               // 1: ids are Long.toString(handle) -> hash computed arithmetically
+    int dbg_skip;                  // debug: bit0 = skip the hash build (timing experiments only)
     long long* dbg;                // optional [grid][16] wall_clock64 stamps of each block's first query
 };
 
@@ -342,13 +344,21 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
 #define FSP_TS(j) ((prm.S_shift >= 0) ? ((j) >> prm.S_shift) : ((j) / S))
     const bool wave_uniform_ts = (prm.S_shift >= 6);  // 64 consecutive tuple slots share one probe step
 
+    // hash entries are (tag(id) << seq_bits) | seq: a failed CAS can tell "other id" from the returned word alone;
+    // tup[] is consulted only when the tags agree (true repeats, or a 2^-(32-seq_bits) false match)
+    const uint32_t seq_mask = (1u << prm.seq_bits) - 1u;
+    const uint32_t tag_max = (0xFFFFFFFFu >> prm.seq_bits) - 1u;   // keeps every entry != kHtEmpty
+    auto id_tag = [&](int32_t id) -> uint32_t {
+        const uint32_t t = (static_cast<uint32_t>(id) * 0x9E3779B1u) >> prm.seq_bits;
+        return t > tag_max ? tag_max : t;
+    };
     // probe the hash for `id`; returns the slot that holds it (must exist)
     auto find_slot = [&](int32_t id) -> uint32_t {
         uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
         const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> prm.ht_shift) | 1u;
         while (true) {
             const uint32_t cur = ht[slot];
-            if (cur != kHtEmpty && tup[cur] == id) return slot;
+            if (cur != kHtEmpty && (cur >> prm.seq_bits) == id_tag(id) && tup[cur & seq_mask] == id) return slot;
             slot = (slot + stp) & ht_mask;
         }
     };
@@ -385,18 +395,15 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
                     if (step < nprobe[td] && pos < pr.w) idv[u] = prm.ids[ids_base[td] + pr.z + pos];
                 }
             }
-            uint32_t slot0[8], first[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int j = j0 + u * nthreads;
-                slot0[u] = 0;
-                if (j >= prm.max_tuples) { idv[u] = -1; continue; }
+                if (j >= prm.max_tuples) continue;
                 int32_t id = idv[u];
                 if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1;
-                idv[u] = id;
                 const int ts = FSP_TS(j);
                 const int sc = probe[ts].y;
-                tup[j] = id;  // written before the CAS below publishes j (same wave: LDS ops stay in order)
+                tup[j] = id;
                 if (id >= 0) tscore[j] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
                 // histogram of (presumed) first occurrences + live tuples per probe step
                 if (wave_uniform_ts) {
@@ -406,34 +413,40 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
                     atomicAdd(&bins[sc], 1);
                     atomicAdd(&stepcnt[ts], 1);
                 }
-                if (id >= 0) slot0[u] = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
             }
-            // optimistic first probe of all 8 tuples: independent CAS ops overlap their LDS round trips
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                first[u] = kHtEmpty;
-                if (idv[u] >= 0) first[u] = atomicCAS(&ht[slot0[u]], kHtEmpty, static_cast<uint32_t>(j0 + u * nthreads));
-            }
-            // the (fewer) tuples whose home slot was taken continue their probe sequence
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (idv[u] < 0 || first[u] == kHtEmpty) continue;   // created at the home slot
-                const int32_t id = idv[u];
-                const uint32_t j = static_cast<uint32_t>(j0 + u * nthreads);
-                uint32_t slot = slot0[u];
-                uint32_t cur = first[u];
-                const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> prm.ht_shift) | 1u;
-                while (true) {
-                    if (tup[cur] == id) {            // same id (whichever occurrence currently sits there)
-                        const uint32_t old = atomicMin(&ht[slot], j);
-                        const uint32_t loser = max(old, j);  // exactly one repeat per meeting
-                        const int pos = atomicAdd(&s_ndup, 1);
-                        if (pos < kDupListMax) duplist[pos] = static_cast<int32_t>(loser);
-                        break;
-                    }
+        }
+        __syncthreads();
+        FSP_STAMP(8);
+        // ---- B1: hash build, ht[slot] = min seq of the id owning the slot.  Every lane walks ITS OWN queue of
+        // tuples (j = tid, tid + nthreads, ...) one probe step per loop trip, so a lane with a long probe
+        // sequence does not stall the other 63: the wave finishes after max-over-lanes of the SUM of probe
+        // lengths instead of the sum of per-tuple maxima.
+        if (!(prm.dbg_skip & 1)) {
+            int j = tid;
+            int32_t id = -1;
+            uint32_t slot = 0, stp = 1, mytag = 0;
+            bool have = false;
+            while (true) {
+                if (!have) {
+                    while (j < prm.max_tuples && (id = tup[j]) < 0) j += nthreads;
+                    if (j >= prm.max_tuples) break;
+                    slot = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
+                    stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> prm.ht_shift) | 1u;
+                    mytag = id_tag(id);
+                    have = true;
+                }
+                const uint32_t val = (mytag << prm.seq_bits) | static_cast<uint32_t>(j);
+                const uint32_t cur = atomicCAS(&ht[slot], kHtEmpty, val);
+                if (cur == kHtEmpty) {                 // created
+                    have = false; j += nthreads;
+                } else if ((cur >> prm.seq_bits) == mytag && tup[cur & seq_mask] == id) {  // same id
+                    const uint32_t old = atomicMin(&ht[slot], val);        // equal tags: ordered by seq
+                    const uint32_t loser = max(old & seq_mask, static_cast<uint32_t>(j));  // exactly one repeat per meeting
+                    const int pos = atomicAdd(&s_ndup, 1);
+                    if (pos < kDupListMax) duplist[pos] = static_cast<int32_t>(loser);
+                    have = false; j += nthreads;
+                } else {
                     slot = (slot + stp) & ht_mask;
-                    cur = atomicCAS(&ht[slot], kHtEmpty, j);
-                    if (cur == kHtEmpty) break;      // created
                 }
             }
         }
@@ -459,8 +472,9 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
             for (int i = tid; i < TP; i += nthreads) stepcnt[i] = 0;
             __syncthreads();
             for (int sl = tid; sl < prm.ht_size; sl += nthreads) {
-                const uint32_t j = ht[sl];
-                if (j == kHtEmpty) continue;
+                const uint32_t hv = ht[sl];
+                const uint32_t j = hv & seq_mask;
+                if (hv == kHtEmpty) continue;
                 tscore[j] |= kFirstFlag;
                 atomicAdd(&bins[tscore[j] & 0x3FFF], 1);
                 atomicAdd(&stepcnt[FSP_TS(static_cast<int>(j))], 1);
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
                 if (!(tscore[j] & kLiveFlag)) continue;      // behind the HARD_CAP cut
                 const int32_t id = tup[j];
                 const int sc = probe[FSP_TS(j)].y;
-                const uint32_t f = ht[find_slot(id)];
+                const uint32_t f = ht[find_slot(id)] & seq_mask;
                 const int first_sc = probe[FSP_TS(static_cast<int>(f))].y;
                 bool improves = sc < first_sc, is_min = improves;
                 for (int l2 = 0; l2 < ndup && (improves || is_min); l2++) {
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
                 for (int j = td * P * S + tid; j < j1; j += nthreads) {
                     const uint16_t v = tscore[j];
                     if (!(v & kLiveFlag) || (v & kFirstFlag)) continue;
-                    const uint32_t f = ht[find_slot(tup[j])];
+                    const uint32_t f = ht[find_slot(tup[j])] & seq_mask;
                     const int sc = probe[FSP_TS(j)].y;
                     const int old = tscore[f] & 0x3FFF;
                     if (sc < old) {

@@ -21,7 +21,7 @@ for it in range(3):
 s = dbg.cpu().numpy().astype(np.float64)
 s = s[s[:, 0] > 0]
 print('blocks', len(s))
-order = [(0,1,"reset+probe list"),(1,2,"stage ids + hash"),(2,9,"repeats/cap/n"),(9,3,"B3 repeats resolve"),(3,11,"C select lvl0/1"),(11,4,"C compaction"),(4,5,"C rank/sort+out"),(5,6,"tail")]
+order = [(0,1,"reset+probe list"),(1,8,"stage ids"),(8,2,"hash build"),(2,9,"repeats/cap/n"),(9,3,"B3 repeats resolve"),(3,11,"C select lvl0/1"),(11,4,"C compaction"),(4,5,"C rank/sort+out"),(5,6,"tail")]
 for a,b,nm in order:
     dt=(s[:,b]-s[:,a])/100.0
     print(f"{nm:24s} mean {dt.mean():8.2f} us   max {dt.max():8.2f}")
