@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512, help="queries timed on the CPU oracle")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="contexts (HIP streams) per GPU that alternate steps; 2 overlaps the latency-bound Route of step i+1 "
+                         "with the bandwidth-bound gather/refine of step i (per-stage times then include the overlap)")
     args = ap.parse_args()
 
     import torch
@@ -88,60 +91,77 @@ def main():
     qrng = np.random.default_rng(args.seed + 1000 + rank)
     Qh = qrng.standard_normal((Q, d), dtype=np.float32)
     cfg = pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=lam, dim=d, seed=13, refinement_limit=B)
-    ctx = pkg.FspannContext(cfg, local_rank)
-    ctx.registry_initialize(X[:1000].astype(np.float64))   # GFunctionRegistry.initialize from the first 1000 vectors
-    ctx.set_id_meta(n)
-    ctx.build_index(X)                                      # GPU coding + partition cut
-    ctx.store_set(X)                                        # plaintext store (decrypt stand-in), fp32
+    ctxs = []
+    for si in range(max(1, args.streams)):
+        c_ = pkg.FspannContext(cfg, local_rank)
+        if si == 0:
+            c_.registry_initialize(X[:1000].astype(np.float64))   # GFunctionRegistry.initialize from the first 1000 vectors
+            c_.set_id_meta(n)
+            c_.build_index(X)                                      # GPU coding (MFMA pre-filter + exact re-check) + partition cut
+        else:                                                      # further streams import the frozen state
+            c_.set_gfunctions(*ctxs[0].get_gfunctions())
+            c_.set_id_meta(n)
+            for td in range(TD):
+                c_.set_index(td, **ctxs[0].get_index(td))
+            c_.finalize()
+        c_.store_set(X)                                            # plaintext store (decrypt stand-in), fp32
+        ctxs.append(c_)
+    ctx = ctxs[0]
     if rank == 0:
         log(f"[bench] setup {time.time() - t0:.1f}s: n={n} d={d} T*D={TD} bits={m * lam} B={B} Q/GPU={Q} k={k}")
 
     # ---------------- device buffers ------------------------------------------------------------------
     q_dev = torch.from_numpy(Qh).to(dev)
-    codes = torch.zeros((Q, TD, W), dtype=torch.int64, device=dev)
-    bad = torch.zeros(Q, dtype=torch.int32, device=dev)
-    sel_ids = torch.full((Q, B), -1, dtype=torch.int32, device=dev)
-    sel_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
-    kept = torch.zeros(Q, dtype=torch.int32, device=dev)
-    raw = torch.zeros(Q, dtype=torch.int32, device=dev)
-    cand = torch.zeros((Q, B, d), dtype=torch.float32, device=dev)
-    out_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
-    out_dist = torch.zeros((Q, k), dtype=torch.float64, device=dev)
-    out_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
-    scored = torch.zeros(Q, dtype=torch.int32, device=dev)
-    gathered = torch.zeros((world * Q, k, 2), dtype=torch.float64, device=dev) if use_dist else None
     from fspann_amd import dist as fdist
+
+    def mkbufs():
+        return dict(codes=torch.zeros((Q, TD, W), dtype=torch.int64, device=dev), bad=torch.zeros(Q, dtype=torch.int32, device=dev),
+                    sel_ids=torch.full((Q, B), -1, dtype=torch.int32, device=dev), sel_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
+                    kept=torch.zeros(Q, dtype=torch.int32, device=dev), raw=torch.zeros(Q, dtype=torch.int32, device=dev),
+                    cand=torch.zeros((Q, B, d), dtype=torch.float32, device=dev), out_ids=torch.zeros((Q, k), dtype=torch.int32, device=dev),
+                    out_dist=torch.zeros((Q, k), dtype=torch.float64, device=dev), out_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
+                    scored=torch.zeros(Q, dtype=torch.int32, device=dev),
+                    gathered=torch.zeros((world * Q, k, 2), dtype=torch.float64, device=dev) if use_dist else None)
+
+    bufs = [mkbufs() for _ in ctxs]
+    out_ids, out_dist, gathered = bufs[0]["out_ids"], bufs[0]["out_dist"], bufs[0]["gathered"]
     torch.cuda.synchronize()
 
-    stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
     F32 = pkg._native.F32
+    step_no = [0]
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
     def step(events=None):
+        si = step_no[0] % len(ctxs)
+        step_no[0] += 1
+        cx, stream, b = ctxs[si], streams[si], bufs[si]
         if events is not None:
             events[0].record(stream)
-        ctx.encode_dev(Q, q_dev.data_ptr(), F32, codes.data_ptr(), 0, bad.data_ptr())
+        cx.encode_dev(Q, q_dev.data_ptr(), F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())
         if events is not None:
             events[1].record(stream)
-        ctx.route_dev(Q, codes.data_ptr(), -1, B, B, sel_ids.data_ptr(), 0, sel_cnt.data_ptr(), kept.data_ptr(), raw.data_ptr())
+        cx.route_dev(Q, b["codes"].data_ptr(), -1, B, B, b["sel_ids"].data_ptr(), 0, b["sel_cnt"].data_ptr(), b["kept"].data_ptr(),
+                     b["raw"].data_ptr())
         if events is not None:
             events[2].record(stream)
-        ctx.store_gather_dev(Q, sel_ids.data_ptr(), sel_cnt.data_ptr(), B, cand.data_ptr())
+        cx.store_gather_dev(Q, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), B, b["cand"].data_ptr())
         if events is not None:
             events[3].record(stream)
-        ctx.refine_dev(Q, q_dev.data_ptr(), F32, cand.data_ptr(), F32, B, sel_ids.data_ptr(), sel_cnt.data_ptr(), k,
-                       out_ids.data_ptr(), out_dist.data_ptr(), out_cnt.data_ptr(), scored.data_ptr())
+        cx.refine_dev(Q, q_dev.data_ptr(), F32, b["cand"].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
+                      b["out_ids"].data_ptr(), b["out_dist"].data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
         if events is not None:
             events[4].record(stream)
         if use_dist:
             # the one collective of the path: all-gather of [Q x k] (id, dist) per rank over RCCL/xGMI
             with torch.cuda.stream(stream):
-                fdist.allgather_topk(out_ids, out_dist, out=gathered)
+                fdist.allgather_topk(b["out_ids"], b["out_dist"], out=b["gathered"])
 
     def barrier():
-        ctx.sync()
+        for c_ in ctxs:
+            c_.sync()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -155,7 +175,8 @@ def main():
     t_start = time.perf_counter()
     for i in range(args.steps):
         step(evs[i])
-    ctx.sync()
+    for c_ in ctxs:
+        c_.sync()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -187,6 +208,17 @@ def main():
     roofline = dict(bound="hbm", kernel="refine_scan_kernel<float,float,32,true>", achieved=round(achieved, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5))
+
+    # Route (probe + select) is the longest stage but is bound by dependent L2 rounds and LDS atomics, not by HBM or
+    # MFMA; its algorithmic bytes (per (t,d) search + rep/id-range fetch + P*S ids) are reported for scale.
+    P_, S_ = 5, 64
+    nparts = (n + S_ - 1) // S_
+    levels = max(1, int(np.ceil(np.log(max(nparts, 2)) / np.log(16))))
+    route_bytes = Q * (TD * (levels * 16 * 16 + (2 * P_ - 1) * (8 * W + 8) + P_ * S_ * 4) + B * 4)
+    route_ms = float(st_mean[1])
+    route_info = dict(kernels="route_probe_kernel + route_select_kernel<true,512>", bound="L2 latency + LDS atomics (integer)",
+                      avg_ms=round(route_ms, 5), algorithmic_bytes_per_launch=int(route_bytes),
+                      achieved_GBs=round(route_bytes / (route_ms * 1e-3) / 1e9, 1))
 
     # ---------------- recall@10 vs exact kNN of the synthetic set (reported, never assumed) ------------
     recall = None
@@ -253,18 +285,20 @@ def main():
             "data": "synthetic N(0,1) fp32 vectors (SIFT-1M shape), exact-kNN ground truth of the synthetic set",
             "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
                        "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q,
-                       "parallelism": f"query-sharded x{world}, index replicated"},
+                       "parallelism": f"query-sharded x{world}, index replicated", "streams_per_gpu": len(ctxs)},
             "recall_at_10": recall,
             "stages_ms": {"encode": round(float(st_mean[0]), 5), "route_select": round(float(st_mean[1]), 5),
                           "stage_candidates": round(float(st_mean[2]), 5), "refine_topk": round(float(st_mean[3]), 5)},
             "roofline": roofline,
+            "route_stage": route_info,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if use_dist and rank == 0:
         # merged result = every rank's top-k in rank order; rank 0's own slice must be intact
         assert torch.equal(gathered[:Q, :, 0].to(torch.int32), out_ids)
-    ctx.close()
+    for c_ in ctxs:
+        c_.close()
     if use_dist:
         dist.destroy_process_group()
 
