@@ -108,8 +108,8 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
 #define FSP_ISSUE(C0)                                                                                              \
     if constexpr (VEC) {                                                                                           \
         _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                          \
-            const int v = tid + i * kRefRows;                                                                      \
-            const int row = v / VPR, cv = v - row * VPR;                                                           \
+            const int v = lane + i * 64;                                                                           \
+            const int row = wave * 64 + v / VPR, cv = v % VPR;                                                     \
             const int col = (C0) + cv * VN;                                                                        \
             if (row < nrows && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(row) * d + col); \
         }                                                                                                          \
@@ -117,24 +117,28 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     double s = 0.0;
     bool ok = true;
     FSP_ISSUE(0)
+    __syncthreads();  // qs visible
+    // Each wave stages and consumes ITS OWN 64 rows: no workgroup barrier in the loop, the four waves drift apart
+    // and overlap each other's load / LDS / fp64 phases.  LDS operations of one wave complete in program order.
+#define FSP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
     for (int c0 = 0; c0 < d; c0 += DC) {
-        __syncthreads();  // previous tile fully consumed (and qs visible on the first pass)
+        FSP_WAVE_SYNC();  // previous tile fully consumed by this wave
         if constexpr (VEC) {
 #pragma unroll
             for (int i = 0; i < VPR; i++) {
-                const int v = tid + i * kRefRows;
-                const int row = v / VPR, cv = v - row * VPR;
+                const int v = lane + i * 64;
+                const int row = wave * 64 + v / VPR, cv = v % VPR;
                 const int col = c0 + cv * VN;
                 if (row < nrows && col < d) *reinterpret_cast<V*>(tile + row * PITCH + cv * VN) = reg[i];
             }
         } else {
-            for (int e = tid; e < kRefRows * DC; e += kRefRows) {
-                const int row = e / DC, cc = e - row * DC;
+            for (int e = lane; e < 64 * DC; e += 64) {
+                const int row = wave * 64 + e / DC, cc = e % DC;
                 if (row < nrows && c0 + cc < d) tile[row * PITCH + cc] = base[static_cast<int64_t>(row) * d + c0 + cc];
             }
         }
         if (c0 + DC < d) { FSP_ISSUE(c0 + DC) }
-        __syncthreads();
+        FSP_WAVE_SYNC();
         if (tid < nrows) {
             const int dc = min(DC, d - c0);
             const TC* myrow = tile + tid * PITCH;
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
         }
     }
 #undef FSP_ISSUE
+#undef FSP_WAVE_SYNC
     const bool qbad = (s_qbad != 0);
     const bool valid = (tid < nrows) && ok && !qbad;
     uint64_t key = kInvalidKey;
