@@ -99,6 +99,8 @@ _SIGS = {
     "fspann_set_id_meta": (_i, [_vp, _i64, _vp, _vp]),
     "fspann_finalize": (_i, [_vp]),
     "fspann_build_index": (_i, [_vp, _i64, _vp, _i, _vp]),
+    "fspann_index_save": (_i, [_vp, C.c_char_p]),
+    "fspann_index_load": (_i, [_vp, C.c_char_p]),
     "fspann_index_dims": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "fspann_get_index": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "fspann_encode": (_i, [_vp, _i64, _vp, _i, _vp, _vp]),

@@ -541,6 +541,89 @@ int fspann_finalize(fspann_ctx* c) {
     return FSPANN_OK;
 }
 
+// ---- frozen-index file: the reference never persists routing state and rebuilds it by decrypting
+// every point (ForwardSecureANNSystem.java:926-948).  Flat little-endian SoA, versioned:
+//   magic "FSPANNIX" | u32 version=1 | cfg {tables,divisions,m,lambda,dim,block_size} | i64 n_ids | u8 decimal_ids
+//   | alpha[TD*m*dim] r[TD*m] omega[TD*m] f64 | java_hash[n_ids] i32 | deleted[n_ids] u8
+//   | per td: i64 n_parts, i64 n_ids_td, min[n_parts] max[n_parts] i64, rep[n_parts*W] u64, off[n_parts+1] i64, ids i32
+}  // extern "C"
+namespace {
+template <typename T> bool wr(FILE* f, const T* p, size_t n) { return n == 0 || std::fwrite(p, sizeof(T), n, f) == n; }
+template <typename T> bool rd(FILE* f, T* p, size_t n) { return n == 0 || std::fread(p, sizeof(T), n, f) == n; }
+}  // namespace
+extern "C" {
+
+int fspann_index_save(fspann_ctx* c, const char* path) {
+    CHECK_CTX(c);
+    if (!path) return fail(FSPANN_E_NULL, "path is null");
+    if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(FSPANN_E_ARG, "cannot open %s for writing", path);
+    bool ok = true;
+    const char magic[8] = {'F', 'S', 'P', 'A', 'N', 'N', 'I', 'X'};
+    const uint32_t ver = 1;
+    const int32_t hdr[6] = {c->cfg.tables, c->cfg.divisions, c->cfg.m, c->cfg.lambda, c->cfg.dim, c->cfg.block_size};
+    const uint8_t dec = c->decimal_ids ? 1 : 0;
+    ok = ok && wr(f, magic, 8) && wr(f, &ver, 1) && wr(f, hdr, 6) && wr(f, &c->n_ids, 1) && wr(f, &dec, 1);
+    ok = ok && wr(f, c->h_alpha.data(), c->h_alpha.size()) && wr(f, c->h_r.data(), c->h_r.size()) && wr(f, c->h_omega.data(), c->h_omega.size());
+    ok = ok && wr(f, c->h_java_hash.data(), c->h_java_hash.size());
+    std::vector<uint8_t> del(static_cast<size_t>(c->n_ids), 0);
+    if (c->d_deleted_bits) {
+        std::vector<uint32_t> bits(static_cast<size_t>((c->n_ids + 31) / 32));
+        if (hipMemcpy(bits.data(), c->d_deleted_bits, bits.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+        for (int64_t i = 0; i < c->n_ids; i++) del[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+    }
+    ok = ok && wr(f, del.data(), del.size());
+    for (int td = 0; td < c->TD && ok; td++) {
+        const int64_t np = static_cast<int64_t>(c->h_min[td].size()), ni = static_cast<int64_t>(c->h_ids[td].size());
+        ok = ok && wr(f, &np, 1) && wr(f, &ni, 1) && wr(f, c->h_min[td].data(), np) && wr(f, c->h_max[td].data(), np) &&
+             wr(f, c->h_rep[td].data(), c->h_rep[td].size()) && wr(f, c->h_off[td].data(), c->h_off[td].size()) && wr(f, c->h_ids[td].data(), ni);
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? FSPANN_OK : fail(FSPANN_E_ARG, "short write to %s", path);
+}
+
+int fspann_index_load(fspann_ctx* c, const char* path) {
+    CHECK_CTX(c);
+    if (!path) return fail(FSPANN_E_NULL, "path is null");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(FSPANN_E_ARG, "cannot open %s", path);
+    struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+    char magic[8];
+    uint32_t ver = 0;
+    int32_t hdr[6];
+    int64_t n_ids = 0;
+    uint8_t dec = 0;
+    if (!rd(f, magic, 8) || std::memcmp(magic, "FSPANNIX", 8) != 0 || !rd(f, &ver, 1) || ver != 1)
+        return fail(FSPANN_E_ARG, "%s is not a version-1 fspann index file", path);
+    if (!rd(f, hdr, 6) || !rd(f, &n_ids, 1) || !rd(f, &dec, 1)) return fail(FSPANN_E_ARG, "truncated header in %s", path);
+    if (hdr[0] != c->cfg.tables || hdr[1] != c->cfg.divisions || hdr[2] != c->cfg.m || hdr[3] != c->cfg.lambda || hdr[4] != c->cfg.dim ||
+        hdr[5] != c->cfg.block_size)
+        return fail(FSPANN_E_STATE, "index file was built for tables=%d divisions=%d m=%d lambda=%d dim=%d (context differs)", hdr[0], hdr[1],
+                    hdr[2], hdr[3], hdr[4]);
+    if (n_ids <= 0 || n_ids >= (1LL << 31)) return fail(FSPANN_E_ARG, "bad n_ids in %s", path);
+    const size_t P = static_cast<size_t>(c->P_total), d = static_cast<size_t>(c->cfg.dim);
+    std::vector<double> alpha(P * d), r(P), w(P);
+    std::vector<int32_t> jh(static_cast<size_t>(n_ids));
+    std::vector<uint8_t> del(static_cast<size_t>(n_ids));
+    if (!rd(f, alpha.data(), alpha.size()) || !rd(f, r.data(), P) || !rd(f, w.data(), P) || !rd(f, jh.data(), jh.size()) || !rd(f, del.data(), del.size()))
+        return fail(FSPANN_E_ARG, "truncated file %s", path);
+    int rc = fspann_set_gfunctions(c, alpha.data(), r.data(), w.data());
+    if (rc) return rc;
+    if ((rc = fspann_set_id_meta(c, n_ids, dec ? nullptr : jh.data(), del.data()))) return rc;
+    for (int td = 0; td < c->TD; td++) {
+        int64_t np = 0, ni = 0;
+        if (!rd(f, &np, 1) || !rd(f, &ni, 1) || np < 0 || ni < 0 || ni > n_ids) return fail(FSPANN_E_ARG, "truncated table %d in %s", td, path);
+        std::vector<int64_t> mn(np), mx(np), off(np + 1);
+        std::vector<uint64_t> rep(static_cast<size_t>(np) * c->W);
+        std::vector<int32_t> ids(ni);
+        if (!rd(f, mn.data(), np) || !rd(f, mx.data(), np) || !rd(f, rep.data(), rep.size()) || !rd(f, off.data(), np + 1) || !rd(f, ids.data(), ni))
+            return fail(FSPANN_E_ARG, "truncated table %d in %s", td, path);
+        if ((rc = fspann_set_index(c, td, np, mn.data(), mx.data(), rep.data(), off.data(), ids.data()))) return rc;
+    }
+    return fspann_finalize(c);
+}
+
 int fspann_index_dims(fspann_ctx* c, int td, int64_t* n_parts, int64_t* n_ids) {
     CHECK_CTX(c);
     if (td < 0 || td >= c->TD) return fail(FSPANN_E_ARG, "td out of range");

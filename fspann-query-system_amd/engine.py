@@ -8,6 +8,7 @@ context's stream.  Product code — never imports oracle/.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -138,6 +139,12 @@ class FspannContext:
         v = v.reshape(-1, self.cfg.dim)
         o = None if order is None else _c(order, np.int32)
         N.check(self.L.fspann_build_index(self._h, v.shape[0], _p(v), _dt(v), _p(o)))
+
+    def save_index(self, path: str):
+        N.check(self.L.fspann_index_save(self._h, os.fsencode(path)))
+
+    def load_index(self, path: str):
+        N.check(self.L.fspann_index_load(self._h, os.fsencode(path)))
 
     def get_index(self, td):
         npart, nid = C.c_int64(), C.c_int64()

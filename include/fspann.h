@@ -112,6 +112,12 @@ int fspann_finalize(fspann_ctx* ctx);
  * host, row h = handle h.  Requires set_gfunctions + set_id_meta first.  Freezes ctx.     */
 int fspann_build_index(fspann_ctx* ctx, int64_t n, const void* vectors, int dtype, const int32_t* order);
 
+/* Frozen-index file: GFunctions + id metadata + every table as flat little-endian SoA.  The reference
+ * never persists routing state and rebuilds it by decrypting every point (ForwardSecureANNSystem.java:926-948).
+ * load() requires a context created with the same tables/divisions/m/lambda/dim and freezes it.              */
+int fspann_index_save(fspann_ctx* ctx, const char* path);
+int fspann_index_load(fspann_ctx* ctx, const char* path);
+
 /* Export a built/imported table (sizes via fspann_index_dims). */
 int fspann_index_dims(fspann_ctx* ctx, int td, int64_t* n_parts, int64_t* n_ids);
 int fspann_get_index(fspann_ctx* ctx, int td, int64_t* min_key, int64_t* max_key, uint64_t* rep,
