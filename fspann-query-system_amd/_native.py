@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "libfspann_hip.so")
 _SRC = os.path.join(_HERE, "csrc")
 
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function", "-pthread"]
 
 OK, E_STATE, E_ARG, E_NULL, E_DEVICE, E_NOMEM, E_RANGE = 0, -1, -2, -3, -4, -5, -6
 F32, F64 = 0, 1

@@ -2,7 +2,9 @@
 // Product code.  No CPU fallback exists: every compute entry point launches a
 // HIP kernel or fails with FSPANN_E_DEVICE.  Nothing here references oracle/.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <mutex>
 #include <new>
 #include <numeric>
@@ -1006,8 +1008,12 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
         bucket[i] = h & static_cast<uint32_t>(capf - 1);
     }
     struct Ent { int64_t key; uint32_t bucket; int32_t pos; };
-    std::vector<Ent> ents(static_cast<size_t>(n));
-    for (int td = 0; td < TD; td++) {
+    // one host thread per table (the cut is independent per (t,d)); the GPU radix-sort version is a "next" item
+    const unsigned hw = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
+    std::atomic<int> next_td{0};
+    auto worker = [&]() {
+      std::vector<Ent> ents(static_cast<size_t>(n));
+      for (int td = next_td.fetch_add(1); td < TD; td = next_td.fetch_add(1)) {
         for (int64_t i = 0; i < n; i++) {
             const uint64_t w0 = codes[(static_cast<size_t>(ord[i]) * TD + td) * W];
             // computeKey: code bit i -> key bit 62-i for i < 63
@@ -1036,6 +1042,14 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
         }
         of[np] = n;
         c->h_table_set[td] = 1;
+      }
+    };
+    {
+        std::vector<std::thread> pool;
+        const unsigned nt = std::min<unsigned>(hw, static_cast<unsigned>(TD));
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
     }
     c->dev_index_dirty = true;
     return fspann_finalize(c);
