@@ -59,6 +59,10 @@ def main():
                          "with the bandwidth-bound gather/refine of step i (per-stage times then include the overlap)")
     args = ap.parse_args()
 
+    # Only the final JSON line may reach stdout: libraries (RCCL prints a version banner) write to fd 1 too.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -118,13 +122,18 @@ def main():
         return dict(codes=torch.zeros((Q, TD, W), dtype=torch.int64, device=dev), bad=torch.zeros(Q, dtype=torch.int32, device=dev),
                     sel_ids=torch.full((Q, B), -1, dtype=torch.int32, device=dev), sel_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
                     kept=torch.zeros(Q, dtype=torch.int32, device=dev), raw=torch.zeros(Q, dtype=torch.int32, device=dev),
-                    cand=torch.zeros((Q, B, d), dtype=torch.float32, device=dev), out_ids=torch.zeros((Q, k), dtype=torch.int32, device=dev),
-                    out_dist=torch.zeros((Q, k), dtype=torch.float64, device=dev), out_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
-                    scored=torch.zeros(Q, dtype=torch.int32, device=dev),
-                    gathered=torch.zeros((world * Q, k, 2), dtype=torch.float64, device=dev) if use_dist else None)
+                    cand=torch.zeros((Q, B, d), dtype=torch.float32, device=dev),
+                    # results are double-buffered so the all-gather of step i (side stream) overlaps step i+1
+                    # (ids and distances of one step live in ONE byte buffer: the merge is a single collective)
+                    topk=[fdist.TopkBuffer(Q, k, dev) for _ in range(2)],
+                    out_cnt=torch.zeros(Q, dtype=torch.int32, device=dev), scored=torch.zeros(Q, dtype=torch.int32, device=dev),
+                    gathered=[fdist.GatheredTopk(world, Q, k, dev) for _ in range(2)] if use_dist else None,
+                    ev_done=[torch.cuda.Event() for _ in range(2)], ev_gath=[torch.cuda.Event() for _ in range(2)], nsteps=0)
 
     bufs = [mkbufs() for _ in ctxs]
-    out_ids, out_dist, gathered = bufs[0]["out_ids"], bufs[0]["out_dist"], bufs[0]["gathered"]
+    out_ids, out_dist = bufs[0]["topk"][0].ids, bufs[0]["topk"][0].dist
+    gathered = bufs[0]["gathered"][0] if use_dist else None
+    side = torch.cuda.Stream(device=dev) if use_dist else None
     torch.cuda.synchronize()
 
     streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
@@ -150,14 +159,22 @@ def main():
         cx.store_gather_dev(Q, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), B, b["cand"].data_ptr())
         if events is not None:
             events[3].record(stream)
+        par = b["nsteps"] & 1
+        b["nsteps"] += 1
+        if use_dist and b["nsteps"] > 2:
+            stream.wait_event(b["ev_gath"][par])      # the all-gather that last read this result buffer has finished
         cx.refine_dev(Q, q_dev.data_ptr(), F32, b["cand"].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
-                      b["out_ids"].data_ptr(), b["out_dist"].data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
+                      b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
         if events is not None:
             events[4].record(stream)
         if use_dist:
-            # the one collective of the path: all-gather of [Q x k] (id, dist) per rank over RCCL/xGMI
-            with torch.cuda.stream(stream):
-                fdist.allgather_topk(b["out_ids"], b["out_dist"], out=b["gathered"])
+            # the one collective of the path: all-gather of [Q x k] (id, dist) per rank over RCCL/xGMI, on a side
+            # stream so that it overlaps the next step's kernels
+            b["ev_done"][par].record(stream)
+            side.wait_event(b["ev_done"][par])
+            with torch.cuda.stream(side):
+                fdist.allgather_topk(b["topk"][par], b["gathered"][par])
+                b["ev_gath"][par].record(side)
 
     def barrier():
         for c_ in ctxs:
@@ -293,10 +310,14 @@ def main():
             "route_stage": route_info,
             "cpu_baseline": cpu,
         }
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist and rank == 0:
         # merged result = every rank's top-k in rank order; rank 0's own slice must be intact
-        assert torch.equal(gathered[:Q, :, 0].to(torch.int32), out_ids)
+        g_ids, g_dist = gathered.split()
+        assert torch.equal(g_ids[:Q], out_ids) and torch.equal(g_dist[:Q], out_dist)
     for c_ in ctxs:
         c_.close()
     if use_dist:

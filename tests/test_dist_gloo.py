@@ -40,7 +40,11 @@ def _worker(rank, world, port, nq, k, ret):
         my_dist = np.full((qloc, k), np.inf)
         my_ids[: hi - lo] = ids_all[lo:hi]
         my_dist[: hi - lo] = dist_all[lo:hi]
-        g_ids, g_dist = fd.allgather_topk(torch.from_numpy(my_ids), torch.from_numpy(my_dist))
+        local = fd.TopkBuffer(qloc, k)
+        local.ids.copy_(torch.from_numpy(my_ids))          # (on the GPU path Refine writes these views directly)
+        local.dist.copy_(torch.from_numpy(my_dist))
+        out = fd.allgather_topk(local, fd.GatheredTopk(world, qloc, k))
+        g_ids, g_dist = out.split()
         ok = np.array_equal(g_ids.numpy()[:nq], ids_all) and np.array_equal(g_dist.numpy()[:nq], dist_all)
         ok = ok and g_ids.shape == (world * qloc, k)
         # shard_bounds covers [0, nq) without gaps or overlap
