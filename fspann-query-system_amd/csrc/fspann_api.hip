@@ -151,7 +151,7 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
                            c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD,
                            tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap);
     } else {
-        constexpr int QB = 2;
+        constexpr int QB = 4;
         dim3 grid(static_cast<unsigned>((nq + QB - 1) / QB), gy);
         hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), grid, dim3(kEncThreads), 0, c->stream, q_dev, nq,
                            c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD,
@@ -232,7 +232,7 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
         pcnt = reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_refine.p) + ((pb + 15) & ~size_t(15)));
     }
     const bool vec = (d % VN == 0) && ((reinterpret_cast<uintptr_t>(cand) & 15) == 0);
-    const size_t lds = static_cast<size_t>((d + 1) & ~1) * 8 + static_cast<size_t>(kRefRows) * (vec ? DC + VN : DC + 1) * sizeof(TC);
+    const size_t lds = std::max<size_t>(static_cast<size_t>(kRefRows) * (vec ? DC + VN : DC + 1) * sizeof(TC), static_cast<size_t>(kRefRows) * 16);
     const unsigned grid = static_cast<unsigned>(nq * nchunks);
     if (vec) {
         auto kern = refine_scan_kernel<TC, TQ, DC, true>;
@@ -802,7 +802,6 @@ int fspann_refine_dev(fspann_ctx* c, int64_t nq, const void* q_dev, int q_dtype,
     if (nq == 0) return FSPANN_OK;
     if (!q_dev || !cand_dev || !cand_ids_dev || !cand_count_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)
         return fail(FSPANN_E_NULL, "refine buffer is null");
-    if (static_cast<int64_t>(c->cfg.dim) * 8 > 96 * 1024) return fail(FSPANN_E_RANGE, "dim too large for the LDS query tile");
 #define FSP_REF(TC, TQ)                                                                                          \
     return launch_refine_t<TC, TQ>(c, nq, static_cast<const TQ*>(q_dev), static_cast<const TC*>(cand_dev), B,    \
                                    cand_ids_dev, cand_count_dev, k, out_ids_dev, out_dist_dev, out_count_dev,    \

@@ -74,13 +74,17 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     constexpr int VN = VecOf<TC>::N;
     constexpr int PITCH = VEC ? DC + VN : DC + 1;   // elements per LDS row
     constexpr int VPR = DC / VN;                    // 16-byte vectors per row per tile
+    // LDS budget: <= 40 KB per workgroup so that FOUR workgroups (all 1024 of a 1024-query batch) are resident per
+    // CU; the top-k scratch (keys, surv) therefore aliases the tile, which is dead once the scan loop is done, and
+    // the query vector is not staged at all: its address is wave-uniform, so it is read through the scalar cache.
     extern __shared__ __align__(16) unsigned char smem[];
-    double* qs = reinterpret_cast<double*>(smem);                                        // [d], padded to even
-    TC* tile = reinterpret_cast<TC*>(smem + static_cast<size_t>((d + 1) & ~1) * 8);      // [kRefRows][PITCH]
-    __shared__ __align__(16) uint64_t keys[kRefRows];
-    __shared__ __align__(16) uint64_t surv[kRefRows];
+    TC* tile = reinterpret_cast<TC*>(smem);                                              // [kRefRows][PITCH]
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                                  // [kRefRows]  (after the scan)
+    uint64_t* surv = keys + kRefRows;                                                    // [kRefRows]
     __shared__ uint64_t s_wcut[kRefRows / 64];
     __shared__ int s_qbad, s_nvalid;
+    __shared__ int s_wbase[kRefRows / 64];
+    const TQ* __restrict__ qrow = q + static_cast<int64_t>(blockIdx.x / nchunks) * d;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -93,15 +97,8 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
 
     if (tid == 0) { s_qbad = 0; s_nvalid = 0; }
     __syncthreads();
-    for (int i = tid; i < ((d + 1) & ~1); i += kRefRows) {
-        double v = 0.0;
-        if (i < d) {
-            const TQ x = q[qi * d + i];
-            if (!finite_t(x)) s_qbad = 1;
-            v = static_cast<double>(x);
-        }
-        qs[i] = v;
-    }
+    for (int i = tid; i < d; i += kRefRows)
+        if (!__builtin_isfinite(qrow[i])) s_qbad = 1;   // QSI.java:137-140: invalid query -> empty result
 
     // register double buffering: tile t+1 is in flight (global -> VGPR) while tile t is consumed from LDS
     V reg[VPR];
@@ -117,7 +114,6 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     double s = 0.0;
     bool ok = true;
     FSP_ISSUE(0)
-    __syncthreads();  // qs visible
     // Each wave stages and consumes ITS OWN 64 rows: no workgroup barrier in the loop, the four waves drift apart
     // and overlap each other's load / LDS / fp64 phases.  LDS operations of one wave complete in program order.
 #define FSP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -148,13 +144,14 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
                     const V xv = *reinterpret_cast<const V*>(myrow + kk);
 #pragma unroll
                     for (int e = 0; e < VN; e += 2) {
-                        const fsp_f64x2 qq = *reinterpret_cast<const fsp_f64x2*>(qs + c0 + kk + e);
+                        const double q0 = static_cast<double>(qrow[c0 + kk + e]);      // uniform address -> scalar load
+                        const double q1 = static_cast<double>(qrow[c0 + kk + e + 1]);
+                        ok = ok && __builtin_isfinite(xv[e]) && __builtin_isfinite(xv[e + 1]);   // v_cmp_class on the raw element
                         const double x0 = vcomp(xv, e), x1 = vcomp(xv, e + 1);   // exact widening
-                        ok = ok && (fabs(x0) <= 1.79769313486231570815e+308) && (fabs(x1) <= 1.79769313486231570815e+308);
-                        const double d0 = qq.x - x0;                             // QSI.java:368
+                        const double d0 = q0 - x0;                               // QSI.java:368
                         const double p0 = d0 * d0;
                         s = s + p0;                                              // QSI.java:369 (in order)
-                        const double d1 = qq.y - x1;
+                        const double d1 = q1 - x1;
                         const double p1 = d1 * d1;
                         s = s + p1;
                     }
@@ -163,7 +160,7 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
                 for (int kk = 0; kk < dc; kk++) {
                     const TC x = myrow[kk];
                     ok = ok && finite_t(x);
-                    const double dd = qs[c0 + kk] - static_cast<double>(x);
+                    const double dd = static_cast<double>(qrow[c0 + kk]) - static_cast<double>(x);
                     const double sq = dd * dd;
                     s = s + sq;
                 }
@@ -176,6 +173,7 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     const bool valid = (tid < nrows) && ok && !qbad;
     uint64_t key = kInvalidKey;
     if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
+    __syncthreads();  // every wave is done with its tile: the region is reused for the top-k scratch
     keys[tid] = key;
     {
         const int c = __popcll(__ballot(valid));
@@ -206,7 +204,6 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
         // ordered compaction (keeps candidate order -> ties stay stable): wave prefix + per-wave base
         const unsigned long long bm = __ballot(sv);
         const int wcount = __popcll(bm);
-        __shared__ int s_wbase[kRefRows / 64];
         if (lane == 0) s_wbase[wave] = wcount;
         __syncthreads();
         int basep = 0, total = 0;
