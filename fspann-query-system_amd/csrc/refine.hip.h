@@ -79,11 +79,9 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     // the query vector is not staged at all: its address is wave-uniform, so it is read through the scalar cache.
     extern __shared__ __align__(16) unsigned char smem[];
     TC* tile = reinterpret_cast<TC*>(smem);                                              // [kRefRows][PITCH]
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                                  // [kRefRows]  (after the scan)
-    uint64_t* surv = keys + kRefRows;                                                    // [kRefRows]
     __shared__ uint64_t s_wcut[kRefRows / 64];
-    __shared__ int s_qbad, s_nvalid;
-    __shared__ int s_wbase[kRefRows / 64];
+    __shared__ int s_qbad;
+    __shared__ int s_wbase[kRefRows / 64], s_wsurvn[kRefRows / 64];
     const TQ* __restrict__ qrow = q + static_cast<int64_t>(blockIdx.x / nchunks) * d;
 
     const int tid = threadIdx.x;
@@ -95,7 +93,9 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     const int nrows = max(0, min(kRefRows, cnt - r0));
     const TC* base = cand + (qi * B + r0) * static_cast<int64_t>(d);
 
-    if (tid == 0) { s_qbad = 0; s_nvalid = 0; }
+    // candidate id of this lane's row: fetched now so the epilogue has no dependent global load
+    const int32_t my_id = (tid < nrows) ? cand_ids[qi * B + r0 + tid] : -1;
+    if (tid == 0) s_qbad = 0;
     __syncthreads();
     for (int i = tid; i < d; i += kRefRows)
         if (!__builtin_isfinite(qrow[i])) s_qbad = 1;   // QSI.java:137-140: invalid query -> empty result
@@ -173,57 +173,79 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     const bool valid = (tid < nrows) && ok && !qbad;
     uint64_t key = kInvalidKey;
     if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
-    __syncthreads();  // every wave is done with its tile: the region is reused for the top-k scratch
-    keys[tid] = key;
-    {
-        const int c = __popcll(__ballot(valid));
-        if (lane == 0 && c) atomicAdd(&s_nvalid, c);
-    }
-    __syncthreads();
-    const int nvalid = s_nvalid;
-    const int eff = min(k, nvalid);
 
     // ---- stable rank by (distance bits, candidate position) -------------------------------------
-    int rank = kRefRows;
-    if (k <= kRefFilterMaxK && nvalid > 2 * k) {
-        // per-wave k-th smallest key = upper bound of the chunk's k-th smallest; only keys <= the tightest
-        // bound (at most k per wave) are ranked against each other.
+    // Scratch lives in each wave's OWN (now dead) tile rows, so the per-wave steps need no workgroup barrier:
+    //   wkeys[64]  the wave's keys           wsurv[64]  the wave's survivors (keys <= the chunk-wide cut)
+    uint64_t* wbase_ptr = reinterpret_cast<uint64_t*>(tile + static_cast<size_t>(wave) * 64 * PITCH);
+    uint64_t* wkeys = wbase_ptr;
+    uint64_t* wsurv = wbase_ptr + 64;
+    auto wave_scratch = [&](int w) { return reinterpret_cast<uint64_t*>(tile + static_cast<size_t>(w) * 64 * PITCH); };
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    wkeys[lane] = key;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int wvalid = __popcll(__ballot(valid));
+    const bool filter = (k <= kRefFilterMaxK);
+    if (filter) {
+        // the wave's k-th smallest key bounds the chunk's k-th smallest from above
         int lrank = 64;
-        if (valid) lrank = rank_among(keys + wave * 64, 64, key, lane);
+        if (valid) lrank = rank_among(wkeys, 64, key, lane);
         const unsigned long long hit = __ballot(valid && lrank == k - 1);
-        if (lane == 0) s_wcut[wave] = kInvalidKey;
-        if (hit) {
-            const int src = __ffsll(static_cast<long long>(hit)) - 1;
-            if (lane == src) s_wcut[wave] = key;
-        }
-        __syncthreads();
-        uint64_t cutk = kInvalidKey;
+        uint64_t wc = kInvalidKey;
+        if (hit) wc = __shfl(key, __ffsll(static_cast<long long>(hit)) - 1);
+        if (lane == 0) s_wcut[wave] = wc;
+    }
+    if (lane == 0) s_wbase[wave] = wvalid;
+    __syncthreads();   // (1) cuts + valid counts of all waves
+    int nvalid = 0;
+    uint64_t cutk = kInvalidKey;
 #pragma unroll
-        for (int w = 0; w < kRefRows / 64; w++) cutk = min(cutk, s_wcut[w]);
+    for (int w = 0; w < kRefRows / 64; w++) {
+        nvalid += s_wbase[w];
+        if (filter) cutk = min(cutk, s_wcut[w]);
+    }
+    const int eff = min(k, nvalid);
+    int rank = kRefRows;
+    if (filter) {
+        // survivors: keys <= the tightest cut (<= k per wave, plus exact ties); each wave keeps its own ordered list
         const bool sv = valid && key <= cutk;
-        // ordered compaction (keeps candidate order -> ties stay stable): wave prefix + per-wave base
         const unsigned long long bm = __ballot(sv);
-        const int wcount = __popcll(bm);
-        if (lane == 0) s_wbase[wave] = wcount;
-        __syncthreads();
-        int basep = 0, total = 0;
+        const int ns = __popcll(bm);
+        const int mypos = __popcll(bm & ((1ull << lane) - 1ull));
+        if (sv) wsurv[mypos] = key;
+        if (lane == 0) {
+            if (ns & 1) wsurv[ns] = kInvalidKey;   // pad to an even count for the 16-byte reads
+            s_wsurvn[wave] = ns;
+        }
+        __syncthreads();   // (2) survivor lists of all waves
+        if (sv) {
+            rank = 0;
+#pragma unroll
+            for (int w = 0; w < kRefRows / 64; w++) {
+                const int n2 = (s_wsurvn[w] + 1) & ~1;
+                const ulonglong2* l2 = reinterpret_cast<const ulonglong2*>(wave_scratch(w) + 64);
+                // earlier waves hold earlier candidate positions: they win ties; later waves lose them
+                if (w < wave) { for (int j = 0; j < n2 / 2; j++) { const ulonglong2 kk = l2[j]; rank += (kk.x <= key) + (kk.y <= key); } }
+                else if (w > wave) { for (int j = 0; j < n2 / 2; j++) { const ulonglong2 kk = l2[j]; rank += (kk.x < key) + (kk.y < key); } }
+                else rank += rank_among(wave_scratch(w) + 64, n2, key, mypos);
+            }
+        }
+    } else if (valid) {
+        rank = 0;
 #pragma unroll
         for (int w = 0; w < kRefRows / 64; w++) {
-            if (w < wave) basep += s_wbase[w];
-            total += s_wbase[w];
+            const ulonglong2* l2 = reinterpret_cast<const ulonglong2*>(wave_scratch(w));
+            if (w < wave) { for (int j = 0; j < 32; j++) { const ulonglong2 kk = l2[j]; rank += (kk.x <= key && kk.x != kInvalidKey) + (kk.y <= key && kk.y != kInvalidKey); } }
+            else if (w > wave) { for (int j = 0; j < 32; j++) { const ulonglong2 kk = l2[j]; rank += (kk.x < key) + (kk.y < key); } }
+            else rank += rank_among(wkeys, 64, key, lane);
         }
-        const int mypos = basep + __popcll(bm & ((1ull << lane) - 1ull));
-        if (sv) surv[mypos] = key;
-        if (tid == 0 && (total & 1)) surv[total] = kInvalidKey;  // pad to an even count
-        __syncthreads();
-        if (sv) rank = rank_among(surv, (total + 1) & ~1, key, mypos);
-    } else if (valid) {
-        rank = rank_among(keys, kRefRows, key, tid);
     }
 
     if (nchunks == 1) {
         if (valid && rank < eff) {
-            out_ids[qi * k + rank] = cand_ids[qi * B + r0 + tid];
+            out_ids[qi * k + rank] = my_id;
             out_dist[qi * k + rank] = __longlong_as_double(static_cast<long long>(key));
         }
         for (int i = eff + tid; i < k; i += kRefRows) {
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
             RefinePartial pp;
             pp.key = key;
             pp.pos = r0 + tid;
-            pp.id = cand_ids[qi * B + r0 + tid];
+            pp.id = my_id;
             partial[(qi * nchunks + chunk) * k + rank] = pp;
         }
         if (tid == 0) {
