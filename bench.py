@@ -54,6 +54,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512, help="queries timed on the CPU oracle")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--query-batches", type=int, default=8,
+                    help="distinct query batches cycled through by the steps (a repeated batch would re-read the same "
+                         "candidate rows out of the 256 MiB Infinity Cache instead of HBM)")
+    ap.add_argument("--candidates", default="store", choices=["store", "dense"],
+                    help="store: refine reads candidate rows from the resident store by id; dense: a gather kernel packs "
+                         "them into [Q][B][d] first (explicit stand-in for the host's load + decrypt)")
     ap.add_argument("--streams", type=int, default=1,
                     help="contexts (HIP streams) per GPU that alternate steps; 2 overlaps the latency-bound Route of step i+1 "
                          "with the bandwidth-bound gather/refine of step i (per-stage times then include the overlap)")
@@ -93,7 +99,9 @@ def main():
     rng = np.random.default_rng(args.seed)
     X = rng.standard_normal((n, d), dtype=np.float32)
     qrng = np.random.default_rng(args.seed + 1000 + rank)
-    Qh = qrng.standard_normal((Q, d), dtype=np.float32)
+    NB = max(1, args.query_batches)
+    Qall = qrng.standard_normal((NB, Q, d), dtype=np.float32)
+    Qh = Qall[0]
     cfg = pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=lam, dim=d, seed=13, refinement_limit=B)
     ctxs = []
     for si in range(max(1, args.streams)):
@@ -115,7 +123,8 @@ def main():
         log(f"[bench] setup {time.time() - t0:.1f}s: n={n} d={d} T*D={TD} bits={m * lam} B={B} Q/GPU={Q} k={k}")
 
     # ---------------- device buffers ------------------------------------------------------------------
-    q_dev = torch.from_numpy(Qh).to(dev)
+    q_all = torch.from_numpy(Qall).to(dev)
+    q_dev = q_all[0]
     from fspann_amd import dist as fdist
 
     def mkbufs():
@@ -139,32 +148,40 @@ def main():
     streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
     F32 = pkg._native.F32
     step_no = [0]
+    dense = (args.candidates == "dense")
 
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
-    def step(events=None):
+    def step(events=None, batch=None):
         si = step_no[0] % len(ctxs)
+        qp = q_all[(step_no[0] // len(ctxs)) % NB].data_ptr() if batch is None else q_all[batch].data_ptr()
         step_no[0] += 1
         cx, stream, b = ctxs[si], streams[si], bufs[si]
         if events is not None:
             events[0].record(stream)
-        cx.encode_dev(Q, q_dev.data_ptr(), F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())
+        cx.encode_dev(Q, qp, F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())
         if events is not None:
             events[1].record(stream)
         cx.route_dev(Q, b["codes"].data_ptr(), -1, B, B, b["sel_ids"].data_ptr(), 0, b["sel_cnt"].data_ptr(), b["kept"].data_ptr(),
                      b["raw"].data_ptr())
         if events is not None:
             events[2].record(stream)
-        cx.store_gather_dev(Q, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), B, b["cand"].data_ptr())
+        if dense:   # explicit stand-in for the host's load + decrypt: pack F_q rows into [Q][B][d]
+            cx.store_gather_dev(Q, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), B, b["cand"].data_ptr())
         if events is not None:
             events[3].record(stream)
         par = b["nsteps"] & 1
         b["nsteps"] += 1
         if use_dist and b["nsteps"] > 2:
             stream.wait_event(b["ev_gath"][par])      # the all-gather that last read this result buffer has finished
-        cx.refine_dev(Q, q_dev.data_ptr(), F32, b["cand"].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
-                      b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
+        if dense:
+            cx.refine_dev(Q, qp, F32, b["cand"].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
+                          b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
+        else:       # candidate rows are read from the resident store by id inside the scan (each row once, no copy)
+            cx.refine_store_dev(Q, qp, F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
+                                b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(), b["out_cnt"].data_ptr(),
+                                b["scored"].data_ptr())
         if events is not None:
             events[4].record(stream)
         if use_dist:
@@ -203,6 +220,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # one more (untimed) step of batch 0 on context 0: its results are what recall and the CPU baseline are checked on
+    step_no[0] = 0
+    bufs[0]["nsteps"] = 0
+    barrier()
+    step(batch=0)
+    barrier()
+
     stage_ms = np.array([[evs[i][j].elapsed_time(evs[i][j + 1]) for j in range(4)] for i in range(args.steps)])
     st_mean = stage_ms.mean(axis=0)
     ms_per_step = elapsed * 1000.0 / args.steps
@@ -218,11 +242,13 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
+            tj = tj.get(args.candidates, {})
             if tj.get("workload") == args.workload and tj.get("Q") == Q:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = dict(bound="hbm", kernel="refine_scan_kernel<float,float,32,true>", achieved=round(achieved, 1),
+    kname = "refine_scan_kernel<float,float,32,true,%s>" % ("false" if dense else "true")
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5))
 
@@ -301,8 +327,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic N(0,1) fp32 vectors (SIFT-1M shape), exact-kNN ground truth of the synthetic set",
             "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
-                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q,
-                       "parallelism": f"query-sharded x{world}, index replicated", "streams_per_gpu": len(ctxs)},
+                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "distinct_query_batches": NB,
+                       "parallelism": f"query-sharded x{world}, index replicated", "streams_per_gpu": len(ctxs),
+                       "candidates": "rows read from the HBM-resident plaintext store by id inside the refine scan" if not dense
+                       else "rows packed into [Q][B][d] by a gather kernel (host decrypt stand-in), then scanned"},
             "recall_at_10": recall,
             "stages_ms": {"encode": round(float(st_mean[0]), 5), "route_select": round(float(st_mean[1]), 5),
                           "stage_candidates": round(float(st_mean[2]), 5), "refine_topk": round(float(st_mean[3]), 5)},

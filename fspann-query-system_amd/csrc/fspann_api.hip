@@ -214,7 +214,7 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     return FSPANN_OK;
 }
 
-template <typename TC, typename TQ, int DC>
+template <typename TC, typename TQ, int DC, bool GATHER>
 int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int64_t B, const int32_t* cand_ids,
                      const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
                      int32_t* scored) {
@@ -234,15 +234,16 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     const bool vec = (d % VN == 0) && ((reinterpret_cast<uintptr_t>(cand) & 15) == 0);
     const size_t lds = std::max<size_t>(static_cast<size_t>(kRefRows) * (vec ? DC + VN : DC + 1) * sizeof(TC), static_cast<size_t>(kRefRows) * 16);
     const unsigned grid = static_cast<unsigned>(nq * nchunks);
+    const int64_t store_n = GATHER ? c->store_n : 0;
     if (vec) {
-        auto kern = refine_scan_kernel<TC, TQ, DC, true>;
+        auto kern = refine_scan_kernel<TC, TQ, DC, true, GATHER>;
         if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, B, d, cand_ids, cand_count, k,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, store_n, B, d, cand_ids, cand_count, k,
                            nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
     } else {
-        auto kern = refine_scan_kernel<TC, TQ, DC, false>;
+        auto kern = refine_scan_kernel<TC, TQ, DC, false, GATHER>;
         if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, B, d, cand_ids, cand_count, k,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, store_n, B, d, cand_ids, cand_count, k,
                            nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
     }
     FSP_HIP(hipGetLastError());
@@ -254,15 +255,15 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     return FSPANN_OK;
 }
 
-template <typename TC, typename TQ>
+template <typename TC, typename TQ, bool GATHER>
 int launch_refine_t(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int64_t B, const int32_t* cand_ids,
                     const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
                     int32_t* scored) {
     constexpr int DC0 = (sizeof(TC) == 4) ? 32 : 16;
     static const int dc_env = [] { const char* e = getenv("FSPANN_REFINE_DC"); return e ? atoi(e) : 0; }();
-    if (dc_env == DC0 * 2) return launch_refine_dc<TC, TQ, DC0 * 2>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
-    if (dc_env == DC0 * 4) return launch_refine_dc<TC, TQ, DC0 * 4>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
-    return launch_refine_dc<TC, TQ, DC0>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
+    if (dc_env == DC0 * 2) return launch_refine_dc<TC, TQ, DC0 * 2, GATHER>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
+    if (dc_env == DC0 * 4) return launch_refine_dc<TC, TQ, DC0 * 4, GATHER>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
+    return launch_refine_dc<TC, TQ, DC0, GATHER>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
 }
 
 #define CHECK_CTX(c)                                                      \
@@ -803,7 +804,7 @@ int fspann_refine_dev(fspann_ctx* c, int64_t nq, const void* q_dev, int q_dtype,
     if (!q_dev || !cand_dev || !cand_ids_dev || !cand_count_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)
         return fail(FSPANN_E_NULL, "refine buffer is null");
 #define FSP_REF(TC, TQ)                                                                                          \
-    return launch_refine_t<TC, TQ>(c, nq, static_cast<const TQ*>(q_dev), static_cast<const TC*>(cand_dev), B,    \
+    return launch_refine_t<TC, TQ, false>(c, nq, static_cast<const TQ*>(q_dev), static_cast<const TC*>(cand_dev), B, \
                                    cand_ids_dev, cand_count_dev, k, out_ids_dev, out_dist_dev, out_count_dev,    \
                                    scored_dev)
     if (cand_dtype == FSPANN_F32 && q_dtype == FSPANN_F32) FSP_REF(float, float);
@@ -863,6 +864,64 @@ int fspann_store_set(fspann_ctx* c, int64_t n, const void* vectors, int dtype) {
     FSP_HIP(hipMemcpy(c->d_store, vectors, bytes, hipMemcpyHostToDevice));
     c->store_dtype = dtype;
     c->store_n = n;
+    return FSPANN_OK;
+}
+
+// Refine straight from the resident store: row j of query qi is store[cand_ids[qi*B + j]].  Same kernel as
+// fspann_refine_dev with the row address taken from the id (no [nq][B][dim] staging copy).
+int fspann_refine_store_dev(fspann_ctx* c, int64_t nq, const void* q_dev, int q_dtype, int64_t B,
+                            const int32_t* cand_ids_dev, const int32_t* cand_count_dev, int k, int32_t* out_ids_dev,
+                            double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev) {
+    CHECK_CTX(c);
+    if (!c->d_store) return fail(FSPANN_E_STATE, "plaintext store not set");
+    if (nq < 0 || B <= 0) return fail(FSPANN_E_ARG, "nq < 0 or B <= 0");
+    if (k <= 0) return fail(FSPANN_E_ARG, "topK must be > 0");  // QueryTokenFactory.java:65
+    if (nq == 0) return FSPANN_OK;
+    if (!q_dev || !cand_ids_dev || !cand_count_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)
+        return fail(FSPANN_E_NULL, "refine buffer is null");
+#define FSP_REF(TC, TQ)                                                                                            \
+    return launch_refine_t<TC, TQ, true>(c, nq, static_cast<const TQ*>(q_dev), static_cast<const TC*>(c->d_store), B, \
+                                         cand_ids_dev, cand_count_dev, k, out_ids_dev, out_dist_dev, out_count_dev, \
+                                         scored_dev)
+    if (c->store_dtype == FSPANN_F32 && q_dtype == FSPANN_F32) FSP_REF(float, float);
+    if (c->store_dtype == FSPANN_F32 && q_dtype == FSPANN_F64) FSP_REF(float, double);
+    if (c->store_dtype == FSPANN_F64 && q_dtype == FSPANN_F32) FSP_REF(double, float);
+    if (c->store_dtype == FSPANN_F64 && q_dtype == FSPANN_F64) FSP_REF(double, double);
+#undef FSP_REF
+    return fail(FSPANN_E_ARG, "unknown dtype");
+}
+
+int fspann_refine_store(fspann_ctx* c, int64_t nq, const void* q, int q_dtype, int64_t B, const int32_t* cand_ids,
+                        const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
+                        int32_t* scored) {
+    CHECK_CTX(c);
+    if (!c->d_store) return fail(FSPANN_E_STATE, "plaintext store not set");
+    if (nq < 0 || B <= 0) return fail(FSPANN_E_ARG, "nq < 0 or B <= 0");
+    if (k <= 0) return fail(FSPANN_E_ARG, "topK must be > 0");
+    if (nq == 0) return FSPANN_OK;
+    if (!q || !cand_ids || !cand_count || !out_ids || !out_dist || !out_count) return fail(FSPANN_E_NULL, "refine buffer is null");
+    if (q_dtype != FSPANN_F32 && q_dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", q_dtype);
+    const size_t qb = static_cast<size_t>(nq) * c->cfg.dim * (q_dtype == FSPANN_F64 ? 8 : 4);
+    const size_t ib = static_cast<size_t>(nq) * B * 4, nb = static_cast<size_t>(nq) * 4;
+    const size_t ob_i = static_cast<size_t>(nq) * k * 4, ob_d = static_cast<size_t>(nq) * k * 8;
+    int rc;
+    if ((rc = ensure(c, c->ws_io[0], qb))) return rc;
+    if ((rc = ensure(c, c->ws_io[2], ib))) return rc;
+    if ((rc = ensure(c, c->ws_io[3], nb * 3))) return rc;
+    if ((rc = ensure(c, c->ws_io[4], ob_i))) return rc;
+    if ((rc = ensure(c, c->ws_io[5], ob_d))) return rc;
+    int32_t* cnts = static_cast<int32_t*>(c->ws_io[3].p);
+    FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, q, qb, hipMemcpyHostToDevice, c->stream));
+    FSP_HIP(hipMemcpyAsync(c->ws_io[2].p, cand_ids, ib, hipMemcpyHostToDevice, c->stream));
+    FSP_HIP(hipMemcpyAsync(cnts, cand_count, nb, hipMemcpyHostToDevice, c->stream));
+    rc = fspann_refine_store_dev(c, nq, c->ws_io[0].p, q_dtype, B, static_cast<int32_t*>(c->ws_io[2].p), cnts, k,
+                                 static_cast<int32_t*>(c->ws_io[4].p), static_cast<double*>(c->ws_io[5].p), cnts + nq, cnts + 2 * nq);
+    if (rc) return rc;
+    FSP_HIP(hipMemcpyAsync(out_ids, c->ws_io[4].p, ob_i, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipMemcpyAsync(out_dist, c->ws_io[5].p, ob_d, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipMemcpyAsync(out_count, cnts + nq, nb, hipMemcpyDeviceToHost, c->stream));
+    if (scored) FSP_HIP(hipMemcpyAsync(scored, cnts + 2 * nq, nb, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipStreamSynchronize(c->stream));
     return FSPANN_OK;
 }
 

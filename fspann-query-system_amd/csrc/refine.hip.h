@@ -64,9 +64,14 @@ __device__ __forceinline__ int rank_among(const uint64_t* keys, int n, uint64_t 
 // LDS tile is ROW-major with a 16-byte pad per row (pitch DC*sizeof(TC)+16): the 16-byte writes of
 // 8 consecutive lanes fill one row segment, and lane r's 16-byte reads of ITS row hit banks
 // (36 r + 4 kk) mod 64 -> conflict-free for ds_read_b128 / ds_write_b128 (MI355X_MICROARCH.md §LDS).
-template <typename TC, typename TQ, int DC, bool VEC>
+//
+// GATHER = false: `cand` is the dense [nq][B][d] block of decrypted candidate rows (the host decrypt loop of
+// QSI:238-271 produced it).  GATHER = true: `cand` is the device-resident plaintext store [store_n][d] and row j of
+// query qi is store[cand_ids[qi*B + j]] — the rows are read from the store exactly once, no staging copy; an id
+// outside [0, store_n) is a point that failed to load (QSI:252-256: skipped, not scored).
+template <typename TC, typename TQ, int DC, bool VEC, bool GATHER>
 __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeof(TC) <= 256 ? 2 : 1))) void refine_scan_kernel(
-    const TQ* __restrict__ q, const TC* __restrict__ cand, int64_t B, int d, const int32_t* __restrict__ cand_ids,
+    const TQ* __restrict__ q, const TC* __restrict__ cand, int64_t store_n, int64_t B, int d, const int32_t* __restrict__ cand_ids,
     const int32_t* __restrict__ cand_count, int k, int nchunks, int32_t* __restrict__ out_ids,
     double* __restrict__ out_dist, int32_t* __restrict__ out_count, int32_t* __restrict__ scored,
     RefinePartial* __restrict__ partial, int32_t* __restrict__ partial_cnt) {
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     const int cnt = static_cast<int>(min(static_cast<int64_t>(cand_count[qi]), B));
     const int r0 = chunk * kRefRows;
     const int nrows = max(0, min(kRefRows, cnt - r0));
-    const TC* base = cand + (qi * B + r0) * static_cast<int64_t>(d);
+    const TC* base = GATHER ? cand : cand + (qi * B + r0) * static_cast<int64_t>(d);
 
     // candidate id of this lane's row: fetched now so the epilogue has no dependent global load
     const int32_t my_id = (tid < nrows) ? cand_ids[qi * B + r0 + tid] : -1;
@@ -102,17 +107,29 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
 
     // register double buffering: tile t+1 is in flight (global -> VGPR) while tile t is consumed from LDS
     V reg[VPR];
+    // source row of each of this lane's 16-byte slots: the block-local row (dense) or the store row (gather), -1 = none
+    int32_t srow[VPR];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int i = 0; i < VPR; i++) {
+            const int row = wave * 64 + (lane + i * 64) / VPR;
+            if constexpr (GATHER) {
+                const int32_t id = (row < nrows) ? cand_ids[qi * B + r0 + row] : -1;
+                srow[i] = (id >= 0 && id < store_n) ? id : -1;
+            } else {
+                srow[i] = (row < nrows) ? row : -1;
+            }
+        }
+    }
 #define FSP_ISSUE(C0)                                                                                              \
     if constexpr (VEC) {                                                                                           \
         _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                          \
-            const int v = lane + i * 64;                                                                           \
-            const int row = wave * 64 + v / VPR, cv = v % VPR;                                                     \
-            const int col = (C0) + cv * VN;                                                                        \
-            if (row < nrows && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(row) * d + col); \
+            const int col = (C0) + ((lane + i * 64) % VPR) * VN;                                                   \
+            if (srow[i] >= 0 && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(srow[i]) * d + col); \
         }                                                                                                          \
     }
     double s = 0.0;
-    bool ok = true;
+    bool ok = GATHER ? (my_id >= 0 && my_id < store_n) : true;
     FSP_ISSUE(0)
     // Each wave stages and consumes ITS OWN 64 rows: no workgroup barrier in the loop, the four waves drift apart
     // and overlap each other's load / LDS / fp64 phases.  LDS operations of one wave complete in program order.
@@ -125,12 +142,19 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
                 const int v = lane + i * 64;
                 const int row = wave * 64 + v / VPR, cv = v % VPR;
                 const int col = c0 + cv * VN;
-                if (row < nrows && col < d) *reinterpret_cast<V*>(tile + row * PITCH + cv * VN) = reg[i];
+                if (srow[i] >= 0 && col < d) *reinterpret_cast<V*>(tile + row * PITCH + cv * VN) = reg[i];
             }
         } else {
             for (int e = lane; e < 64 * DC; e += 64) {
                 const int row = wave * 64 + e / DC, cc = e % DC;
-                if (row < nrows && c0 + cc < d) tile[row * PITCH + cc] = base[static_cast<int64_t>(row) * d + c0 + cc];
+                if (row < nrows && c0 + cc < d) {
+                    int64_t sr = row;
+                    if constexpr (GATHER) {
+                        const int32_t id = cand_ids[qi * B + r0 + row];
+                        sr = (id >= 0 && id < store_n) ? id : -1;
+                    }
+                    if (sr >= 0) tile[row * PITCH + cc] = base[sr * d + c0 + cc];
+                }
             }
         }
         if (c0 + DC < d) { FSP_ISSUE(c0 + DC) }

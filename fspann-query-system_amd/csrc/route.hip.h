@@ -127,6 +127,7 @@ __device__ __forceinline__ uint32_t decimal_string_hash_dev(uint32_t v) {
 
 constexpr int kProbeThreads = 256;
 constexpr int kDupListMax = 512;
+constexpr int kStageU = 12;                 // id loads in flight per lane while staging (one round trip for 10 tuples per lane)
 constexpr uint16_t kLiveFlag = 0x4000u;   // tscore: tuple slot holds a live (non-deleted) id
 
 // First index b in [0, nb) with prefix(b) >= need, computed by ONE wave (nb <= 1024).
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams 
 // Kernel 2: stage ids, dedupe, Java order, select.  One workgroup per query.
 // ------------------------------------------------------------------------------------------
 template <bool kLds, int kThreads>
-__global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm, const int4* __restrict__ probe_in,
+__global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams prm, const int4* __restrict__ probe_in,
                                                                 const int32_t* __restrict__ nprobe_in) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -342,7 +343,6 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
 
 #define FSP_STAMP(i) do { if (prm.dbg && tid == 0 && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
 #define FSP_TS(j) ((prm.S_shift >= 0) ? ((j) >> prm.S_shift) : ((j) / S))
-    const bool wave_uniform_ts = (prm.S_shift >= 6);  // 64 consecutive tuple slots share one probe step
 
     // hash entries are (tag(id) << seq_bits) | seq: a failed CAS can tell "other id" from the returned word alone;
     // tup[] is consulted only when the tags agree (true repeats, or a 2^-(32-seq_bits) false match)
@@ -381,37 +381,41 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
         __syncthreads();
         FSP_STAMP(1);
 
-        // ---- A2 + B1 fused: stage ids, build the hash: ht[slot] = min seq of the id owning the slot ----
-        for (int j0 = tid; j0 < prm.max_tuples; j0 += nthreads * 8) {
-            int32_t idv[8];
+        // ---- A2: stage ids.  One wave-iteration = 64 consecutive positions of ONE probed partition, so all the
+        // index arithmetic (table, step, id range, score) is wave-uniform (scalar) and the id load is one
+        // coalesced 256-byte row; kStageU iterations are in flight per wave.
+        {
+            const int SP = (S + 63) >> 6;                 // 64-lane pieces per partition
+            const int nitems = TP * SP;
+            const int nwv = nthreads >> 6;
+            for (int it0 = wave; it0 < nitems; it0 += nwv * kStageU) {
+                int32_t idv[kStageU];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int j = j0 + u * nthreads;
-                idv[u] = -1;
-                if (j < prm.max_tuples) {
-                    const int ts = FSP_TS(j), pos = j - ts * S;
-                    const int td = ts / P, step = ts - td * P;
-                    const int4 pr = probe[ts];
-                    if (step < nprobe[td] && pos < pr.w) idv[u] = prm.ids[ids_base[td] + pr.z + pos];
+                for (int u = 0; u < kStageU; u++) {
+                    const int it = it0 + u * nwv;
+                    idv[u] = -1;
+                    if (it < nitems) {
+                        const int ts = it / SP, pos = (it - ts * SP) * 64 + lane;
+                        const int td = ts / P, step = ts - td * P;
+                        const int4 pr = probe[ts];
+                        if (step < nprobe[td] && pos < pr.w && pos < S) idv[u] = prm.ids[ids_base[td] + pr.z + pos];
+                    }
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int j = j0 + u * nthreads;
-                if (j >= prm.max_tuples) continue;
-                int32_t id = idv[u];
-                if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1;
-                const int ts = FSP_TS(j);
-                const int sc = probe[ts].y;
-                tup[j] = id;
-                if (id >= 0) tscore[j] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
-                // histogram of (presumed) first occurrences + live tuples per probe step
-                if (wave_uniform_ts) {
+                for (int u = 0; u < kStageU; u++) {
+                    const int it = it0 + u * nwv;
+                    if (it >= nitems) continue;           // wave-uniform
+                    const int ts = it / SP, pos = (it - ts * SP) * 64 + lane;
+                    if (pos >= S) continue;
+                    const int j = ts * S + pos;
+                    int32_t id = idv[u];
+                    if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1;
+                    const int sc = probe[ts].y;
+                    tup[j] = id;
+                    if (id >= 0) tscore[j] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
+                    // histogram of (presumed) first occurrences + live tuples per probe step: one atomic per wave
                     const int c1 = __popcll(__ballot(id >= 0));
                     if (lane == 0 && c1) { atomicAdd(&bins[sc], c1); atomicAdd(&stepcnt[ts], c1); }
-                } else if (id >= 0) {
-                    atomicAdd(&bins[sc], 1);
-                    atomicAdd(&stepcnt[ts], 1);
                 }
             }
         }
@@ -624,18 +628,34 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
         FSP_STAMP(11);
         // compaction of the surviving candidates: score < star, or score == star && bucket bin <= b1
         uint64_t* gs = prm.g_sort ? prm.g_sort + static_cast<int64_t>(blockIdx.x) * prm.g_sort_stride : sortbuf;
-        for (int j = tid; j < prm.max_tuples; j += nthreads) {
-            const uint16_t v = tscore[j];
-            if (!(v & kFirstFlag)) continue;
-            const int sc = v & 0x3FFFu;
-            if (sc > star) continue;
-            const uint32_t bfield = bucket_field(tup[j]);
-            if (sc == star && lvl1 && static_cast<int>(bfield >> (kBucketBits - 10)) > b1) continue;
-            const uint64_t key = (static_cast<uint64_t>(sc) << (kBucketBits + kSeqBits)) |
-                                 (static_cast<uint64_t>(bfield) << kSeqBits) | static_cast<uint32_t>(j);
-            const int pos = atomicAdd(&s_fill, 1);
-            if (pos < prm.sort_cap) sortbuf[pos] = key;
-            else gs[pos] = key;  // only reachable when g_sort exists (host guarantees capacity)
+        for (int j0 = 0; j0 < prm.max_tuples; j0 += nthreads) {     // uniform trip count: the ballots below need every lane
+            const int j = j0 + tid;
+            bool take = false;
+            uint64_t key = 0;
+            if (j < prm.max_tuples) {
+                const uint16_t v = tscore[j];
+                const int sc = v & 0x3FFFu;
+                if ((v & kFirstFlag) && sc <= star) {
+                    const uint32_t bfield = bucket_field(tup[j]);
+                    if (!(sc == star && lvl1 && static_cast<int>(bfield >> (kBucketBits - 10)) > b1)) {
+                        take = true;
+                        key = (static_cast<uint64_t>(sc) << (kBucketBits + kSeqBits)) |
+                              (static_cast<uint64_t>(bfield) << kSeqBits) | static_cast<uint32_t>(j);
+                    }
+                }
+            }
+            // one LDS atomic per wave instead of one per survivor (they would all hit the same address)
+            const unsigned long long bm = __ballot(take);
+            int basepos = 0;
+            if (bm) {
+                if (lane == 0) basepos = atomicAdd(&s_fill, __popcll(bm));
+                basepos = __shfl(basepos, 0);
+            }
+            if (take) {
+                const int pos = basepos + __popcll(bm & ((1ull << lane) - 1ull));
+                if (pos < prm.sort_cap) sortbuf[pos] = key;
+                else gs[pos] = key;  // only reachable when g_sort exists (host guarantees capacity)
+            }
         }
         __syncthreads();
         FSP_STAMP(4);
@@ -696,6 +716,8 @@ __global__ __launch_bounds__(kThreads) void route_select_kernel(RouteParams prm,
             if (prm.out_kept) prm.out_kept[qi] = n;
             if (prm.out_raw) prm.out_raw[qi] = n + s_raw;
         }
+        // LDS-only barrier: the next query may reuse the scratch, but nothing has to wait for this query's global
+        // result stores (a __syncthreads() would add their full write latency to every query)
         __syncthreads();
         FSP_STAMP(6);
     }

@@ -220,6 +220,23 @@ class FspannContext:
                                      _p(out_dist), _p(out_count), _p(scored)))
         return dict(ids=out_ids, dist=out_dist, count=out_count, scored=scored)
 
+    def refine_store(self, q, cand_ids, cand_count, k):
+        """Refine with rows read from the resident store by id (no staging copy)."""
+        ci = _c(cand_ids, np.int32)
+        nq, B = ci.shape
+        q = np.ascontiguousarray(q)
+        if q.dtype not in (np.float32, np.float64):
+            q = q.astype(np.float64)
+        q = q.reshape(nq, self.cfg.dim)
+        cc = _c(cand_count, np.int32).reshape(nq)
+        out_ids = np.empty((nq, k), np.int32)
+        out_dist = np.empty((nq, k), np.float64)
+        out_count = np.empty(nq, np.int32)
+        scored = np.empty(nq, np.int32)
+        N.check(self.L.fspann_refine_store(self._h, nq, _p(q), _dt(q), B, _p(ci), _p(cc), k, _p(out_ids),
+                                           _p(out_dist), _p(out_count), _p(scored)))
+        return dict(ids=out_ids, dist=out_dist, count=out_count, scored=scored)
+
     # -- plaintext store (test / bench harness) --------------------------------------
     def store_set(self, vectors):
         v = np.ascontiguousarray(vectors)
@@ -239,6 +256,11 @@ class FspannContext:
 
     def store_gather_dev(self, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr):
         N.check(self.L.fspann_store_gather_dev(self._h, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr))
+
+    def refine_store_dev(self, nq, q_ptr, q_dtype, B, cand_ids_ptr, cand_count_ptr, k, out_ids_ptr, out_dist_ptr,
+                         out_count_ptr, scored_ptr=0):
+        N.check(self.L.fspann_refine_store_dev(self._h, nq, q_ptr, q_dtype, B, cand_ids_ptr, cand_count_ptr, k,
+                                               out_ids_ptr, out_dist_ptr, out_count_ptr, scored_ptr or None))
 
     def refine_dev(self, nq, q_ptr, q_dtype, cand_ptr, cand_dtype, B, cand_ids_ptr, cand_count_ptr, k, out_ids_ptr,
                    out_dist_ptr, out_count_ptr, scored_ptr=0):

@@ -179,6 +179,16 @@ int fspann_refine_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtyp
 int fspann_store_set(fspann_ctx* ctx, int64_t n, const void* vectors, int dtype /* stored as given */);
 int fspann_store_gather_dev(fspann_ctx* ctx, int64_t nq, const int32_t* sel_ids_dev, const int32_t* sel_count_dev,
                             int64_t B, void* cand_dev /* [nq][B][dim], store dtype */);
+/* Refine with the candidate rows read from the resident store by id (row j of query q =
+ * store[cand_ids[q][j]], j < cand_count[q]): the same scan + top-K as fspann_refine_dev without the
+ * [nq][B][dim] staging copy.  An id outside [0, n) is a point that failed to load (QSI:252-256):
+ * skipped, not scored.  FSPANN_E_STATE when no store has been set.                            */
+int fspann_refine_store(fspann_ctx* ctx, int64_t nq, const void* q, int q_dtype, int64_t B, const int32_t* cand_ids,
+                        const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
+                        int32_t* scored);
+int fspann_refine_store_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtype, int64_t B,
+                            const int32_t* cand_ids_dev, const int32_t* cand_count_dev, int k, int32_t* out_ids_dev,
+                            double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev);
 const void* fspann_store_dev_ptr(fspann_ctx* ctx, int* dtype);
 
 /* ---- device memory helpers (so non-torch callers can own HBM buffers) ------------------- */

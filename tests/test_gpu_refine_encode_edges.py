@@ -167,3 +167,36 @@ def test_native_registry_initialize_matches_oracle(pkg, oracle):
         a, r, w = ctx.get_gfunctions()
     assert np.array_equal(w, w0) and np.array_equal(r, r0)      # exact fp64 projections on the GPU
     assert np.array_equal(a, a0)                                # same libm on this box; else compare to 1e-15
+
+
+@pytest.mark.parametrize("B,k,d,dt", [(256, 10, 128, np.float32), (600, 40, 30, np.float32), (64, 10, 960, np.float32),
+                                      (256, 10, 128, np.float64), (300, 7, 33, np.float64)])
+def test_refine_from_resident_store(pkg, oracle, B, k, d, dt):
+    """fspann_refine_store: rows addressed by id in the resident store == the dense [nq][B][d] refine == oracle.
+    Ids outside the store are points that failed to load (QSI:252-256): skipped, not scored."""
+    rng = np.random.default_rng(B + k + d)
+    n, nq = 5000, 6
+    store = rng.standard_normal((n, d)).astype(dt)
+    store[17, d // 2] = np.inf                      # a corrupt stored row is skipped like any non-finite candidate
+    q = rng.standard_normal((nq, d)).astype(dt)
+    ids = rng.integers(0, n, (nq, B)).astype(np.int32)
+    ids[0, 5] = 17
+    ids[1, 0] = -1
+    ids[1, B - 1] = n                               # one past the end
+    ids[2, 3] = 2**31 - 1
+    cnt = np.array([B, B, B, 0, 1, B // 2 + 1], np.int32)
+    bad = (ids < 0) | (ids >= n)
+    dense = store[np.where(bad, 0, ids)].copy()
+    dense[bad] = np.nan                             # the oracle skips non-finite rows: same effect as "not loaded"
+    ref_ids, ref_dist, ref_cnt = oracle.refine(q.astype(np.float64), dense.astype(np.float64), ids, cnt, k)
+    with _ctx(pkg, d, B=B) as ctx:
+        with pytest.raises(pkg.FspannStateError):
+            ctx.refine_store(q, ids, cnt, k)        # no store yet
+        ctx.store_set(store)
+        res = ctx.refine_store(q, ids, cnt, k)
+        via_dense = ctx.refine(q, dense, ids, cnt, k)
+    for key in ("count", "ids", "dist", "scored"):
+        assert np.array_equal(res[key], via_dense[key]), key
+    assert np.array_equal(res["count"], ref_cnt)
+    assert np.array_equal(res["ids"], ref_ids)
+    assert np.array_equal(res["dist"], ref_dist)
