@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--query-batches", type=int, default=8,
                     help="distinct query batches cycled through by the steps (a repeated batch would re-read the same "
                          "candidate rows out of the 256 MiB Infinity Cache instead of HBM)")
+    ap.add_argument("--route-counters", action="store_true",
+                    help="also produce lastCandKept / rawSeen per query (forces the full select)")
     ap.add_argument("--candidates", default="store", choices=["store", "dense"],
                     help="store: refine reads candidate rows from the resident store by id; dense: a gather kernel packs "
                          "them into [Q][B][d] first (explicit stand-in for the host's load + decrypt)")
@@ -163,8 +165,10 @@ def main():
         cx.encode_dev(Q, qp, F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())
         if events is not None:
             events[1].record(stream)
-        cx.route_dev(Q, b["codes"].data_ptr(), -1, B, B, b["sel_ids"].data_ptr(), 0, b["sel_cnt"].data_ptr(), b["kept"].data_ptr(),
-                     b["raw"].data_ptr())
+        # lastCandKept / rawSeen are profiler counters of the reference (QSI metrics), not inputs of Refine: they are
+        # only computed on request (--route-counters), which forces the full select over every probed partition
+        cx.route_dev(Q, b["codes"].data_ptr(), -1, B, B, b["sel_ids"].data_ptr(), 0, b["sel_cnt"].data_ptr(),
+                     b["kept"].data_ptr() if args.route_counters else 0, b["raw"].data_ptr() if args.route_counters else 0)
         if events is not None:
             events[2].record(stream)
         if dense:   # explicit stand-in for the host's load + decrypt: pack F_q rows into [Q][B][d]
@@ -259,7 +263,9 @@ def main():
     levels = max(1, int(np.ceil(np.log(max(nparts, 2)) / np.log(16))))
     route_bytes = Q * (TD * (levels * 16 * 16 + (2 * P_ - 1) * (8 * W + 8) + P_ * S_ * 4) + B * 4)
     route_ms = float(st_mean[1])
-    route_info = dict(kernels="route_probe_kernel + route_select_kernel<true,512>", bound="L2 latency + LDS atomics (integer)",
+    rinfo = ctx.last_route_info()
+    route_info = dict(kernels="route_probe_kernel + " + ("route_select_lazy_kernel<256> (bounded select; %d of %d queries handed to the full select)"
+                                                         % (rinfo["overflowed"], Q) if rinfo["lazy"] else "route_select_kernel<true,512>"), bound="L2 latency + LDS atomics (integer)",
                       avg_ms=round(route_ms, 5), algorithmic_bytes_per_launch=int(route_bytes),
                       achieved_GBs=round(route_bytes / (route_ms * 1e-3) / 1e9, 1))
 
@@ -327,7 +333,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic N(0,1) fp32 vectors (SIFT-1M shape), exact-kNN ground truth of the synthetic set",
             "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
-                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "distinct_query_batches": NB,
+                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "distinct_query_batches": NB, "route_counters": bool(args.route_counters),
                        "parallelism": f"query-sharded x{world}, index replicated", "streams_per_gpu": len(ctxs),
                        "candidates": "rows read from the HBM-resident plaintext store by id inside the refine scan" if not dense
                        else "rows packed into [Q][B][d] by a gather kernel (host decrypt stand-in), then scanned"},

@@ -12,6 +12,7 @@
 #include "encode.hip.h"
 #include "refine.hip.h"
 #include "route.hip.h"
+#include "route_lazy.hip.h"
 
 using namespace fspann;
 
@@ -92,6 +93,31 @@ int upload_index(fspann_ctx* c) {
     FSP_HIP(hipMemcpy(c->d_rep, rep.data(), rep.size() * 8, hipMemcpyHostToDevice));
     if (!off.empty()) FSP_HIP(hipMemcpy(c->d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     FSP_HIP(hipMemcpy(c->d_ids, idv.data(), idv.size() * 4, hipMemcpyHostToDevice));
+    // inverse id map for the bounded select: inv[td][id] = position of id in table td's id list.  A table that holds
+    // an id twice (never produced by PIS.insert, but importable) cannot be inverted: the bounded select stays off.
+    free_devt(c->d_inv);
+    if (c->n_ids > 0 && static_cast<int64_t>(TD) * c->n_ids < (1LL << 33)) {
+        std::vector<int32_t> inv(static_cast<size_t>(TD) * static_cast<size_t>(c->n_ids), -1);
+        std::atomic<bool> ok{true};
+        std::vector<std::thread> th;
+        const int nth = std::max(1, std::min<int>(TD, static_cast<int>(std::thread::hardware_concurrency())));
+        for (int w = 0; w < nth; w++)
+            th.emplace_back([&, w] {
+                for (int td = w; td < TD; td += nth) {
+                    int32_t* row = inv.data() + static_cast<size_t>(td) * static_cast<size_t>(c->n_ids);
+                    const std::vector<int32_t>& v = c->h_ids[td];
+                    for (size_t i = 0; i < v.size(); i++) {
+                        if (v[i] < 0 || v[i] >= c->n_ids || row[v[i]] != -1) { ok = false; break; }
+                        row[v[i]] = static_cast<int32_t>(i);
+                    }
+                }
+            });
+        for (auto& t : th) t.join();
+        if (ok) {
+            FSP_HIP(hipMalloc(&c->d_inv, inv.size() * 4));
+            FSP_HIP(hipMemcpy(c->d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     c->dev_index_dirty = false;
     return FSPANN_OK;
 }
@@ -167,9 +193,12 @@ struct RoutePlan {
     int grid;
     int threads;
     int64_t g_sort_stride;
+    // bounded select (route_lazy.hip.h)
+    int lazy, lazy_cap, lz_ht_size, lz_grid;
+    size_t lz_lds_bytes;
 };
 
-int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, RoutePlan& pl) {
+int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, RoutePlan& pl, bool want_counters = true) {
     pl.P = effective_probes(c, probe_override);
     pl.S = c->cfg.block_size;
     pl.S_shift = ((pl.S & (pl.S - 1)) == 0) ? __builtin_ctz(pl.S) : -1;
@@ -211,6 +240,24 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     const int per_cu = std::max<int>(1, static_cast<int>(static_cast<size_t>(c->lds_limit) / (pl.lds_bytes + 512)));
     pl.grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * std::min(per_cu, 4)));
     pl.g_sort_stride = (pl.sort_cap < full_sort) ? full_sort : 0;
+    // ---- bounded select: legal when the first `limit` entries do not depend on how many ids exist ----------------
+    pl.lazy = 0;
+    const bool cap_fixed = java_final_cap_host(c->cap0, mt) == c->cap0;       // HashMap never resizes
+    const bool legal = c->d_inv && !pl.need_cap && cap_fixed && !want_counters && limit <= 512 && pl.lds_mode;
+    if (legal && c->route_mode != 1 && (c->route_mode == 2 || static_cast<int64_t>(limit) * 4 <= mt)) {
+        const char* ce = getenv("FSPANN_ROUTE_LAZY_CAP");   // tests: distinct ids one query may hold before it is handed back
+        const int cap_env = ce ? atoi(ce) : 0;
+        const size_t lds = static_cast<size_t>(kLzHtSize) * 8 + TP * 16 + 4096 + 4096 + (TP + 2) * 8 + (TP + 1) * 4 + 8 +
+                           static_cast<size_t>(c->TD) * 8 + ((TP * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kLzEntries) * 2 + 4096 + 16;
+        if (TP < 32768 && lds <= budget) {
+            pl.lazy = 1;
+            pl.lazy_cap = (cap_env > 0) ? std::min(cap_env, kLzEntries) : kLzEntries;
+            pl.lz_ht_size = kLzHtSize;
+            pl.lz_lds_bytes = lds;
+            const int lz_per_cu = std::max<int>(1, std::min<int>(8, static_cast<int>(static_cast<size_t>(c->lds_limit) / (lds + 256))));
+            pl.lz_grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * lz_per_cu));
+        }
+    }
     return FSPANN_OK;
 }
 
@@ -345,7 +392,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
     free_dev(c->d_store);
-    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p);
+    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_devt(c->d_inv);
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -528,6 +575,7 @@ int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, c
             FSP_HIP(hipMemcpy(c->d_deleted_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
         }
     }
+    if (n_ids != c->n_ids) { free_devt(c->d_inv); c->dev_index_dirty = true; }   // the inverse id map is [TD][n_ids]
     c->n_ids = n_ids;
     return FSPANN_OK;
 }
@@ -712,7 +760,7 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     if (!ids_dev || !count_dev) return fail(FSPANN_E_NULL, "output buffer is null");
     if (limit <= 0) return fail(FSPANN_E_ARG, "limit must be > 0");
     RoutePlan pl;
-    int rc = plan_route(c, probe_override, nq, limit, pl);
+    int rc = plan_route(c, probe_override, nq, limit, pl, kept_dev != nullptr || raw_seen_dev != nullptr);
     if (rc) return rc;
     const int64_t need = std::min<int64_t>(limit, pl.maxcand);
     if (cap < need) return fail(FSPANN_E_RANGE, "cap %lld < min(limit, worst case) = %lld", (long long)cap, (long long)need);
@@ -734,6 +782,13 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     { const char* e = getenv("FSPANN_ROUTE_DBG_SKIP"); p.dbg_skip = e ? atoi(e) : 0; }
     p.decimal_ids = c->decimal_ids ? 1 : 0;
     p.out_cap = cap; p.out_ids = ids_dev; p.out_score = score_dev; p.out_count = count_dev; p.out_kept = kept_dev; p.out_raw = raw_seen_dev;
+    if (pl.lazy) {
+        if ((rc = ensure(c, c->ws_ovf, static_cast<size_t>(nq) * 4 + 256))) return rc;
+        p.inv = c->d_inv; p.n_ids = c->n_ids; p.lazy_cap = pl.lazy_cap; p.lz_ht_size = pl.lz_ht_size;
+        p.lz_ht_shift = 32 - __builtin_ctz(pl.lz_ht_size);
+        p.ovf_count = static_cast<int32_t*>(c->ws_ovf.p);
+        p.ovf_list = p.ovf_count + 64;
+    }
     // kernel 1: search + probe order, one lane group per (query, table)
     const size_t TPn = static_cast<size_t>(c->TD) * pl.P;
     const size_t probe_bytes = static_cast<size_t>(nq) * TPn * 16, np_bytes = static_cast<size_t>(nq) * c->TD * 4;
@@ -757,6 +812,20 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
                                     static_cast<int>(pl.lds_bytes)));                                                    \
         hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(THR), pl.lds_bytes, c->stream, p, probe_dev, nprobe_dev);           \
     } while (0)
+    c->last_route_lazy = pl.lazy;
+    if (pl.lazy) {
+        auto lk = route_select_lazy_kernel<kLzThreads>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(lk, dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p, probe_dev, nprobe_dev);
+        FSP_HIP(hipGetLastError());
+        // queries the bounded select handed back (none, normally): the full select over the overflow list
+        p.qcount = p.ovf_count; p.qlist = p.ovf_list;
+        pl.grid = std::min(pl.grid, 128);
+    }
     if (pl.lds_mode) { if (pl.threads == 1024) FSP_LAUNCH_SEL(true, 1024); else FSP_LAUNCH_SEL(true, 512); }
     else { if (pl.threads == 1024) FSP_LAUNCH_SEL(false, 1024); else FSP_LAUNCH_SEL(false, 512); }
 #undef FSP_LAUNCH_SEL
@@ -782,7 +851,8 @@ int fspann_route(fspann_ctx* c, int64_t nq, const uint64_t* codes, int probe_ove
     int32_t* cnt = static_cast<int32_t*>(c->ws_io[3].p);
     FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, codes, cb, hipMemcpyHostToDevice, c->stream));
     rc = fspann_route_dev(c, nq, static_cast<const uint64_t*>(c->ws_io[0].p), probe_override, limit, cap,
-                          static_cast<int32_t*>(c->ws_io[1].p), static_cast<int32_t*>(c->ws_io[2].p), cnt, cnt + nq, cnt + 2 * nq);
+                          static_cast<int32_t*>(c->ws_io[1].p), static_cast<int32_t*>(c->ws_io[2].p), cnt, kept ? cnt + nq : nullptr,
+                          raw_seen ? cnt + 2 * nq : nullptr);
     if (rc) return rc;
     FSP_HIP(hipMemcpyAsync(ids, c->ws_io[1].p, ob, hipMemcpyDeviceToHost, c->stream));
     if (score) FSP_HIP(hipMemcpyAsync(score, c->ws_io[2].p, ob, hipMemcpyDeviceToHost, c->stream));
@@ -953,6 +1023,30 @@ int fspann_store_gather_dev(fspann_ctx* c, int64_t nq, const int32_t* sel_ids_de
     return FSPANN_OK;
 }
 
+// Route select path: 0 = auto, 1 = always the full select (route_select_kernel), 2 = the bounded select whenever its
+// preconditions hold (route_lazy.hip.h).  All modes return identical lists.
+int fspann_set_route_mode(fspann_ctx* c, int mode) {
+    if (!c) return fail(FSPANN_E_NULL, "ctx is null");
+    if (mode < 0 || mode > 2) return fail(FSPANN_E_ARG, "route mode must be 0, 1 or 2");
+    c->route_mode = mode;
+    return FSPANN_OK;
+}
+// Which select the last fspann_route[_dev] ran: *lazy = 1 for the bounded select; *overflowed = queries it handed back
+// to the full select (synchronises the stream).
+int fspann_last_route_info(fspann_ctx* c, int* lazy, int* overflowed) {
+    CHECK_CTX(c);
+    if (lazy) *lazy = c->last_route_lazy;
+    if (overflowed) {
+        *overflowed = 0;
+        if (c->last_route_lazy && c->ws_ovf.p) {
+            FSP_HIP(hipStreamSynchronize(c->stream));
+            int32_t v = 0;
+            FSP_HIP(hipMemcpy(&v, c->ws_ovf.p, 4, hipMemcpyDeviceToHost));
+            *overflowed = v;
+        }
+    }
+    return FSPANN_OK;
+}
 // Encode path selection: 0 = auto (MFMA pre-filter for nq >= 4096, exact fp64 otherwise), 1 = exact fp64 VALU only,
 // 2 = always MFMA fp32 GEMM + exact re-check.  All modes produce bit-identical hashes and codes.
 int fspann_set_encode_mode(fspann_ctx* c, int mode) {

@@ -102,6 +102,10 @@ struct fspann_ctx {
     uint64_t* d_rep = nullptr;    // [total_parts][W]
     int32_t* d_off = nullptr;     // per table nparts+1 entries, relative to ids_base
     int32_t* d_ids = nullptr;
+    int32_t* d_inv = nullptr;        // [TD][n_ids] inverse id map for the bounded select (null: a table holds an id twice)
+    int route_mode = 0;              // 0 auto, 1 always route_select_kernel, 2 bounded select whenever its preconditions hold
+    fspann::DevBuf ws_ovf;
+    int last_route_lazy = 0;         // 1 if the last fspann_route[_dev] ran the bounded select
     int64_t total_parts = 0, total_ids = 0;
 
     // id metadata

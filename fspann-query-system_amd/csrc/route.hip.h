@@ -66,6 +66,15 @@ struct RouteParams {
     int32_t* out_kept;
     int32_t* out_raw;
     int decimal_ids;               // 1: ids are Long.toString(handle) -> hash computed arithmetically
+    // bounded ("lazy") select, route_lazy.hip.h
+    const int32_t* inv;            // [TD][n_ids] position of an id in table td's id list (-1 = absent)
+    int64_t n_ids;
+    int lazy_cap;                  // tuples one query may insert before it is handed to route_select_kernel
+    int lz_ht_size, lz_ht_shift;
+    int32_t* ovf_count;            // overflow list written by the lazy kernel ...
+    int32_t* ovf_list;
+    const int32_t* qcount;         // ... and consumed by route_select_kernel (qlist mode: only these queries)
+    const int32_t* qlist;
     int dbg_skip;                  // debug: bit0 = skip the hash build (timing experiments only)
     long long* dbg;                // optional [grid][16] wall_clock64 stamps of each block's first query
 };
@@ -181,6 +190,7 @@ __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams 
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp_in_wave * G));
     int32_t* w3 = reinterpret_cast<int32_t*>(smem) + static_cast<size_t>(grp_in_block) * nd * 3;  // [nd][3]
 
+    if (prm.ovf_count && blockIdx.x == 0 && tid == 0) *prm.ovf_count = 0;   // stream-ordered before the select kernels
     const int64_t item = static_cast<int64_t>(blockIdx.x) * gpb + grp_in_block;  // (q, td) flattened
     const int64_t nitems = prm.nq * TD;
     const bool in_range = item < nitems;
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
 
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
 
-#define FSP_STAMP(i) do { if (prm.dbg && tid == 0 && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define FSP_STAMP(i) do { if (prm.dbg && tid == 0 && qq == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
 #define FSP_TS(j) ((prm.S_shift >= 0) ? ((j) >> prm.S_shift) : ((j) / S))
 
     // hash entries are (tag(id) << seq_bits) | seq: a failed CAS can tell "other id" from the returned word alone;
@@ -363,7 +373,9 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
         }
     };
 
-    for (int64_t qi = blockIdx.x; qi < prm.nq; qi += gridDim.x) {
+    const int64_t nq_eff = prm.qlist ? static_cast<int64_t>(*prm.qcount) : prm.nq;
+    for (int64_t qq = blockIdx.x; qq < nq_eff; qq += gridDim.x) {
+        const int64_t qi = prm.qlist ? static_cast<int64_t>(prm.qlist[qq]) : qq;
         FSP_STAMP(0);
         // ---- reset (16-byte stores) + probe list of this query -------------------------------
         {
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
         __syncthreads();
         FSP_STAMP(4);
         const int nsel = s_fill;
-        if (tid == 0 && prm.dbg && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + 15] = nsel;
+        if (tid == 0 && prm.dbg && qq == blockIdx.x) prm.dbg[blockIdx.x * 16 + 15] = nsel;
         const int nout = min(nsel, prm.limit);
         if (nsel <= kRankSortMax - 128 && prm.sort_cap >= kRankSortMax) {
             // all-pairs rank: keys are unique (seq is), so rank = #smaller keys; no barriers.

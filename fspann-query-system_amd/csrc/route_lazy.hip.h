@@ -1,0 +1,483 @@
+// route_lazy.hip.h — Route select when only the first `limit` entries of the Java-ordered candidate list are
+// wanted (QSI stage A.5, QSI:169-214) and neither counter (lastCandKept / rawSeen) is asked for.
+//
+// The list is ordered by (score, HashMap bucket, first insertion) and an id's score is the MINIMUM Hamming distance
+// over the probed partitions that hold it (PIS:726-753), every id of one probed partition carrying that partition's
+// distance.  So the first `limit` entries are decided by the probed partitions with the SMALLEST distances, and
+// inside the distance level that crosses `limit` by the ids with the smallest buckets:
+//
+//   1. sort the <= T*D*P probed partitions of the query by distance (all-pairs rank, a few hundred elements);
+//   2. walk the distance LEVELS in ascending order, keeping an LDS hash  id -> (min distance, bucket):
+//        a. whole levels whose tuples cannot reach `limit` distinct ids are inserted as they are;
+//        b. the level that can cross `limit` is pre-filtered: histogram of its not-yet-present ids over the top
+//           10 bits of the bucket, cut at the `need`-th id, and only ids at or below the cut are inserted (the
+//           histogram counts an id once per partition holding it, so if the cut yields too few DISTINCT ids it is
+//           moved up and the step repeats; when the whole level is in, the walk goes on to the next level).
+//      Afterwards every id that can be among the first `limit` is in the hash with its exact score, and the hash
+//      holds about `limit` + (level size / 1024) entries — not T*D*P*S;
+//   3. rank the entries by (score, bucket) — 32-bit keys, all-pairs, no barriers — and write ranks < limit;
+//   4. "first insertion" matters only between entries that agree on (score, bucket) — a handful per query.  For
+//      those the reference's insertion sequence is recomputed exactly from the inverse id map (inv[td][id] =
+//      position of id in table td's id list): the first table, in Java order, whose probed partitions cover that
+//      position.  That also accounts for occurrences in partitions this kernel never loaded.
+//
+// Preconditions (checked by the host, otherwise route_select_kernel runs): the HARD_CAP cannot trigger
+// (T*D*P*S < HARD_CAP), the HashMap never resizes (T*D*P*S <= 0.75 * initial capacity, so the bucket of an id does
+// not depend on how many ids were inserted), no table holds an id twice, out_kept == out_raw == NULL, limit <= 512.
+// A query whose entries do not fit (degenerate hashCodes: one bucket bin holding hundreds of ids) is appended to an
+// overflow list and redone by route_select_kernel (qlist mode) — same results, just slower.
+#pragma once
+#include "route.hip.h"
+
+namespace fspann {
+
+constexpr uint64_t kLzEmpty = ~0ull;
+constexpr int kLzThreads = 256;
+constexpr int kLzHtSize = 2048;     // hash slots (64-bit entries): <= kLzEntries live entries, load <= 0.5
+constexpr int kLzEntries = 1024;    // distinct ids one query may hold
+constexpr int kLzSortMax = 896;     // entries the rank pass takes (padding to a multiple of 8 per slice stays < 1024)
+constexpr int kLzCollMax = 256;     // entries sharing (score, bucket) with another one
+constexpr int kLzStageU = 4;        // probed partitions in flight per wave
+constexpr int kLzKeep = 8;          // partitions of the crossing level one wave keeps in registers
+
+// wave_find_cut for exactly 1024 bins starting at a 16-byte aligned address: each lane takes 16 bins with four
+// 16-byte reads and walks ITS bins out of registers (no second LDS pass).  One wave; result in every lane.
+__device__ __forceinline__ int wave_cut1024(const int32_t* bins, int need, int lane, int* before) {
+    const int4* b4 = reinterpret_cast<const int4*>(bins) + lane * 4;
+    const int4 v0 = b4[0], v1 = b4[1], v2 = b4[2], v3 = b4[3];
+    const int vals[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += vals[i];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    const int excl = incl - sum;
+    const unsigned long long bm = __ballot((incl >= need) && (excl < need));
+    if (bm == 0) {   // total < need: everything before the last bin
+        *before = __shfl(incl, 63) - __shfl(v3.w, 63);
+        return 1023;
+    }
+    const int src = __ffsll(static_cast<long long>(bm)) - 1;
+    int cum = excl, bb = 15;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (!found) {
+            if (cum + vals[i] >= need) { bb = i; found = true; }
+            else cum += vals[i];
+        }
+    }
+    *before = __shfl(cum, src);
+    return __shfl(lane * 16 + bb, src);
+}
+
+template <int kThreads>
+__global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RouteParams prm, const int4* __restrict__ probe_in,
+                                                                        const int32_t* __restrict__ nprobe_in) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    constexpr int nthreads = kThreads;
+    constexpr int nwv = kThreads / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int TD = prm.TD, P = prm.P, S = prm.S;
+    const int TP = TD * P;
+    const int SP = (S + 63) >> 6;                 // 64-lane pieces per partition
+
+    size_t o = 0;
+    uint64_t* ht = reinterpret_cast<uint64_t*>(smem + o);        o += static_cast<size_t>(kLzHtSize) * 8;
+    int4* plist = reinterpret_cast<int4*>(smem + o);             o += static_cast<size_t>(TP) * 16;
+    uint32_t* pre = reinterpret_cast<uint32_t*>(smem + o);       o += 1024 * 4;          // (score << 20 | bucket) per entry
+    int32_t* bins = reinterpret_cast<int32_t*>(smem + o);        o += 1024 * 4;
+    uint2* pkv = reinterpret_cast<uint2*>(smem + o);             o += (static_cast<size_t>(TP) + 2) * 8;   // {distance << 16 | probe index, size}, padded to even
+    int32_t* pcs = reinterpret_cast<int32_t*>(smem + o);         o += (static_cast<size_t>(TP) + 1) * 4;
+    o = (o + 7) & ~size_t(7);
+    int64_t* ids_base = reinterpret_cast<int64_t*>(smem + o);    o += static_cast<size_t>(TD) * 8;
+    uint16_t* ord = reinterpret_cast<uint16_t*>(smem + o);       o += (static_cast<size_t>(TP) * 2 + 3) & ~size_t(3);
+    uint16_t* ulist = reinterpret_cast<uint16_t*>(smem + o);     o += static_cast<size_t>(kLzEntries) * 2;   // hash slots of the entries
+    uint16_t* rk = reinterpret_cast<uint16_t*>(smem + o);        o += 1024 * 2;   // entries per (score, bucket) rank: > 1 = collision
+    uint16_t* lrank = reinterpret_cast<uint16_t*>(smem + o);     // [1024] (score, bucket) rank of each entry
+    // collision records alias the histogram (free once the levels are in): element, prefix rank, id, sequence
+    int32_t* c_elem = bins;
+    int32_t* c_lt = bins + kLzCollMax;
+    int32_t* c_id = bins + 2 * kLzCollMax;
+    int32_t* c_seq = bins + 3 * kLzCollMax;
+
+    __shared__ int s_u, s_R, s_ncoll, s_bad, s_b, s_cnt;
+    constexpr uint32_t ht_mask = kLzHtSize - 1;
+    constexpr int ht_shift = 32 - 11;
+    static_assert(kLzHtSize == 2048, "ht_shift");
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
+    for (int i = tid; i < kLzHtSize; i += nthreads) ht[i] = kLzEmpty;
+
+    // HashMap geometry is fixed (no resize can happen, see preconditions)
+    const int capbits = 31 - __clz(prm.cap0);
+    const uint32_t bmask = static_cast<uint32_t>(prm.cap0 - 1);
+    const int bshift = kBucketBits - capbits;
+    auto bucket_field = [&](int32_t id) -> uint32_t {
+        uint32_t h = prm.decimal_ids ? decimal_string_hash_dev(static_cast<uint32_t>(id)) : static_cast<uint32_t>(prm.java_hash[id]);
+        h ^= (h >> 16);                              // HashMap.hash()
+        return (h & bmask) << bshift;
+    };
+    // is `id` already an entry?  (an entry of an earlier level: its score is lower, this occurrence changes nothing)
+    auto present = [&](int32_t id) -> bool {
+        uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> ht_shift;
+        const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> ht_shift) | 1u;
+        for (int tries = 0; tries < kLzHtSize; tries++) {
+            const uint64_t e = ht[slot];
+            if (e == kLzEmpty) return false;
+            if (static_cast<uint32_t>(e >> 32) == static_cast<uint32_t>(id)) return true;
+            slot = (slot + stp) & ht_mask;
+        }
+        return false;
+    };
+    // ht[id] = min(ht[id], low) with low = score << 20 | bucket; returns true when the entry was created (*slot_out)
+    auto insert = [&](int32_t id, uint32_t low, uint32_t* slot_out) -> bool {
+        const uint64_t mine = (static_cast<uint64_t>(static_cast<uint32_t>(id)) << 32) | low;
+        uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> ht_shift;
+        const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> ht_shift) | 1u;
+        // <= kLzEntries < kLzHtSize entries and an odd step over a power-of-two table: an empty slot or the id itself
+        // is met within kLzHtSize trips (the bound only guards against a host-side slip)
+        for (int tries = 0; tries < kLzHtSize; tries++) {
+            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&ht[slot]), kLzEmpty, mine);
+            if (old == kLzEmpty) { *slot_out = slot; return true; }
+            if (static_cast<uint32_t>(old >> 32) == static_cast<uint32_t>(id)) {
+                if (static_cast<uint32_t>(old) > low) atomicMin(reinterpret_cast<unsigned long long*>(&ht[slot]), mine);
+                return false;
+            }
+            slot = (slot + stp) & ht_mask;
+        }
+        s_bad = 1;
+        return false;
+    };
+
+#define LZ_STAMP(i) do { if (prm.dbg && tid == 0 && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+// Every live tuple of the sorted probes [RA, RB): BODY sees `id` (>= 0 when live and not deleted, else -1) and `sc`;
+// kLzStageU partitions are in flight per wave (one coalesced 256-byte id row each).  Trip counts are wave-uniform.
+#define LZ_FOR_TUPLES(RA, RB, BODY)                                                                                   \
+    do {                                                                                                              \
+        const int nit_ = ((RB) - (RA)) * SP;                                                                          \
+        for (int it0_ = wave; it0_ < nit_; it0_ += nwv * kLzStageU) {                                                 \
+            int32_t idv_[kLzStageU];                                                                                  \
+            int scv_[kLzStageU];                                                                                      \
+            _Pragma("unroll") for (int v_ = 0; v_ < kLzStageU; v_++) {                                                \
+                const int it_ = it0_ + v_ * nwv;                                                                      \
+                idv_[v_] = -1; scv_[v_] = 0;                                                                          \
+                if (it_ < nit_) {                                                                                     \
+                    const int rr_ = (RA) + it_ / SP, pos_ = (it_ % SP) * 64 + lane;                                   \
+                    const int pi_ = ord[rr_];                                                                         \
+                    const int4 pr_ = plist[pi_];                                                                      \
+                    scv_[v_] = pr_.y;                                                                                 \
+                    if (pos_ < pr_.w) idv_[v_] = prm.ids[ids_base[pi_ / P] + pr_.z + pos_];                           \
+                }                                                                                                     \
+            }                                                                                                         \
+            _Pragma("unroll") for (int v_ = 0; v_ < kLzStageU; v_++) {                                                \
+                if (it0_ + v_ * nwv >= nit_) continue;                                                                \
+                int32_t id = idv_[v_];                                                                                \
+                const int sc = scv_[v_]; (void)sc;                                                                    \
+                if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1; /* PIS:739 */ \
+                BODY                                                                                                  \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+// insert + record the new entries of this wave-trip (one LDS atomic per wave)
+#define LZ_INSERT(COND, LOW)                                                                                          \
+    do {                                                                                                              \
+        bool created_ = false;                                                                                        \
+        uint32_t slot_ = 0;                                                                                           \
+        if (COND) created_ = insert(id, (LOW), &slot_);                                                               \
+        const unsigned long long bm_ = __ballot(created_);                                                            \
+        if (bm_) {                                                                                                    \
+            int base_ = 0;                                                                                            \
+            if (lane == 0) base_ = atomicAdd(&s_u, __popcll(bm_));                                                    \
+            base_ = __shfl(base_, 0);                                                                                 \
+            const int at_ = base_ + __popcll(bm_ & lt_mask);                                                          \
+            if (created_ && at_ < kLzEntries) ulist[at_] = static_cast<uint16_t>(slot_);                              \
+        }                                                                                                             \
+    } while (0)
+
+    for (int64_t qi = blockIdx.x; qi < prm.nq; qi += gridDim.x) {
+        LZ_STAMP(0);
+        // ---- probe list of this query; unused steps get an impossible partition and sort last ------------------
+        for (int i = tid; i < TP; i += nthreads) {
+            const int td = i / P, step = i - td * P;
+            int4 e = make_int4(-1, 0x7FFF, 0, 0);
+            if (step < nprobe_in[qi * TD + td]) e = probe_in[qi * TP + i];
+            plist[i] = e;
+            pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
+        }
+        if (tid == 0) { s_u = 0; s_R = TP; s_ncoll = 0; s_bad = 0; pkv[TP] = make_uint2(0xFFFFFFFFu, 0u); }
+        __syncthreads();
+        LZ_STAMP(1);
+        // ---- 1. order the probed partitions by (distance, Java order); prefix sums of their sizes ----------------
+        for (int i = tid; i < TP; i += nthreads) {
+            const uint2 me = pkv[i];
+            const uint32_t mk = me.x;
+            int rank = 0, cum = 0;
+            const uint4* kv4 = reinterpret_cast<const uint4*>(pkv);    // two probes per 16-byte LDS read (broadcast)
+#pragma unroll 4
+            for (int j = 0; j < (TP + 1) / 2; j++) {
+                const uint4 kv = kv4[j];
+                const bool b0 = kv.x < mk, b1 = kv.z < mk;
+                rank += b0 + b1;
+                cum += (b0 ? kv.y : 0u) + (b1 ? kv.w : 0u);
+            }
+            ord[rank] = static_cast<uint16_t>(i);
+            pcs[rank] = cum;
+            if ((mk >> 16) == 0x7FFFu) atomicMin(&s_R, rank);   // unused steps sort last: the first of them ends the list
+            if (rank == TP - 1) pcs[TP] = cum + static_cast<int>(me.y);
+        }
+        __syncthreads();
+        LZ_STAMP(2);
+        const int R = s_R;                           // valid probes occupy sorted positions [0, R)
+        bool overflow = false;
+        int r0 = 0, u = 0;
+        int dbg_outer = 0, dbg_inner = 0, dbg_reload = 0, dbg_nitb = 0;
+        // ---- 2. walk the distance levels ---------------------------------------------------------------------------
+        while (r0 < R && u < prm.limit) {
+            const int need = prm.limit - u;
+            // r_fit = last level boundary whose cumulated tuples stay <= need; r_nofit = the boundary after it (the end of
+            // the level that can cross `limit`).  Every wave computes the same values: the loop is wave-uniform.
+            int r_fit = r0, r_nofit = R;
+            for (int c0 = r0 + 1; c0 <= R; c0 += 64) {
+                const int r = c0 + lane;
+                const bool bnd = (r <= R) && (r == R || (pkv[ord[r]].x >> 16) != (pkv[ord[r - 1]].x >> 16));
+                const unsigned long long bb = __ballot(bnd);
+                const unsigned long long bf = __ballot(bnd && (pcs[r] - pcs[r0] <= need));
+                if (bf) r_fit = c0 + 63 - __clzll(static_cast<long long>(bf));
+                if (bb & ~bf) { r_nofit = c0 + __ffsll(static_cast<long long>(bb & ~bf)) - 1; break; }   // later ones do not fit either
+            }
+            const int rb0 = r_fit, rb1 = (r_fit < R) ? r_nofit : R;   // [rb0, rb1): the level that can cross (may be empty)
+            // one global round trip for both: the ids of the crossing level are requested now and stay in registers
+            // (at most kLzKeep partitions per wave; larger levels are re-read when needed)
+            const int nitB = (rb1 - rb0) * SP;
+            const bool keep = (nitB > 0) && (nitB <= nwv * kLzKeep);
+            dbg_outer++; dbg_reload += (nitB > 0 && !keep); dbg_nitb = max(dbg_nitb, nitB);
+            int32_t idr[kLzKeep];
+            uint32_t bfr[kLzKeep];
+            if (keep) {
+#pragma unroll
+                for (int k = 0; k < kLzKeep; k++) {
+                    const int it = wave + k * nwv;
+                    idr[k] = -1;
+                    if (it < nitB) {
+                        const int pi = ord[rb0 + it / SP], pos = (it % SP) * 64 + lane;
+                        const int4 pr = plist[pi];
+                        if (pos < pr.w) idr[k] = prm.ids[ids_base[pi / P] + pr.z + pos];
+                    }
+                }
+            }
+            for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;
+            if (r_fit > r0) {
+                // a. whole levels, at most `need` tuples: u stays <= limit
+                LZ_FOR_TUPLES(r0, r_fit, {
+                    uint32_t low = 0;
+                    if (id >= 0) low = (static_cast<uint32_t>(sc) << kBucketBits) | bucket_field(id);
+                    LZ_INSERT(id >= 0, low);
+                });
+            }
+            __syncthreads();
+            LZ_STAMP(8);
+            u = s_u;
+            if (s_bad) { overflow = true; break; }
+            if (u >= prm.limit || rb0 >= R) {
+                r0 = rb0;
+                __syncthreads();                     // s_u has been read by everyone before it moves again
+                continue;
+            }
+            // b. the level [rb0, rb1) can cross `limit`: pre-filter by bucket
+            const uint32_t sc_hi = (pkv[ord[rb0]].x >> 16) << kBucketBits;     // the level's distance
+            if (keep) {
+#pragma unroll
+                for (int k = 0; k < kLzKeep; k++) {
+                    int32_t id = idr[k];
+                    if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1;   // PIS:739
+                    bfr[k] = 0;
+                    if (id >= 0) {
+                        bfr[k] = bucket_field(id);
+                        if (present(id)) id = -1;                              // entry of an earlier level: nothing to do
+                        else atomicAdd(&bins[bfr[k] >> (kBucketBits - 10)], 1);
+                    }
+                    idr[k] = id;
+                }
+            } else {
+                LZ_FOR_TUPLES(rb0, rb1, {
+                    if (id >= 0 && !present(id)) atomicAdd(&bins[bucket_field(id) >> (kBucketBits - 10)], 1);
+                });
+            }
+            __syncthreads();
+            LZ_STAMP(10);
+            int lo = 0;
+            while (true) {
+                if (wave == 0) {
+                    int before = 0;
+                    const int b = (lo == 0) ? wave_cut1024(bins, prm.limit - u, lane, &before)
+                                            : lo + wave_find_cut(bins + lo, 1024 - lo, prm.limit - u, lane, &before);
+                    if (lane == 0) { s_b = b; s_cnt = before + bins[b]; }
+                }
+                __syncthreads();
+                LZ_STAMP(11);
+                dbg_inner++;
+                const int b = s_b;
+                if (u + s_cnt > prm.lazy_cap) { overflow = true; break; }   // lazy_cap <= kLzEntries
+                if (keep) {
+                    // all inserts of this wave first, then ONE LDS atomic for the wave's new entries.  An id in range is
+                    // finished either way (created, or already an entry): idr = -2 marks "created", bfr then holds the slot
+                    int total = 0;
+#pragma unroll
+                    for (int k = 0; k < kLzKeep; k++) {
+                        const int bin = static_cast<int>(bfr[k] >> (kBucketBits - 10));
+                        if (idr[k] >= 0 && bin >= lo && bin <= b) {
+                            uint32_t slot = 0;
+                            const bool c = insert(idr[k], sc_hi | bfr[k], &slot);
+                            idr[k] = c ? -2 : -1;
+                            if (c) bfr[k] = slot;
+                        }
+                        total += __popcll(__ballot(idr[k] == -2));
+                    }
+                    if (total) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_u, total);
+                        base = __shfl(base, 0);
+#pragma unroll
+                        for (int k = 0; k < kLzKeep; k++) {
+                            const bool c = (idr[k] == -2);
+                            const unsigned long long bm = __ballot(c);
+                            const int at = base + __popcll(bm & lt_mask);
+                            if (c && at < kLzEntries) ulist[at] = static_cast<uint16_t>(bfr[k]);
+                            if (c) idr[k] = -1;
+                            base += __popcll(bm);
+                        }
+                    }
+                } else {
+                    LZ_FOR_TUPLES(rb0, rb1, {
+                        uint32_t bfld = 0;
+                        bool in = false;
+                        if (id >= 0) {
+                            bfld = bucket_field(id);
+                            const int bin = static_cast<int>(bfld >> (kBucketBits - 10));
+                            in = (bin >= lo && bin <= b);
+                        }
+                        LZ_INSERT(in, sc_hi | bfld);
+                    });
+                }
+                __syncthreads();
+                LZ_STAMP(12);
+                u = s_u;
+                if (s_bad) { overflow = true; break; }
+                if (u >= prm.limit || b >= 1023) break;
+                lo = b + 1;
+                __syncthreads();                     // s_u / s_b have been read by everyone before they move again
+            }
+            if (overflow) break;
+            r0 = rb1;
+            __syncthreads();
+        }
+        LZ_STAMP(3);
+        // ---- 3. rank the entries by (score, bucket) ---------------------------------------------------------------
+        const int nsel = u;
+        if (nsel > kLzSortMax) overflow = true;
+        if (!overflow) {
+            const int nout = min(nsel, prm.limit);
+            // element i is ranked by `parts` cooperating lanes, each over a slice of the keys; with more entries than
+            // lanes a lane carries two elements through the same scan
+            int parts = 1;
+            while (parts < 16 && nsel * parts * 2 <= nthreads) parts <<= 1;
+            const int len = (((nsel + parts - 1) / parts) + 7) & ~7;   // slice length, multiple of 8
+            const int padded = parts * len;                            // <= kLzSortMax + 7 < 1024
+            for (int i = tid; i < padded; i += nthreads) pre[i] = (i < nsel) ? static_cast<uint32_t>(ht[ulist[i]]) : 0xFFFFFFFFu;
+            for (int i = tid; i < 512; i += nthreads) reinterpret_cast<uint32_t*>(rk)[i] = 0u;
+            __syncthreads();
+            LZ_STAMP(4);
+            const int per_pass = nthreads / parts;
+            for (int base = 0; base < nsel; base += 2 * per_pass) {
+                const int i0 = base + tid / parts, i1 = i0 + per_pass, part = tid % parts;
+                const uint32_t my0 = (i0 < nsel) ? pre[i0] : 0u, my1 = (i1 < nsel) ? pre[i1] : 0u;
+                int lt0 = 0, lt1 = 0;
+                const uint4* p4 = reinterpret_cast<const uint4*>(pre + part * len);
+                if (base + per_pass < nsel) {        // block-uniform: second elements exist
+                    for (int j = 0; j < len / 4; j += 2) {
+                        const uint4 a = p4[j], b = p4[j + 1];
+                        lt0 += (a.x < my0) + (a.y < my0) + (a.z < my0) + (a.w < my0) + (b.x < my0) + (b.y < my0) + (b.z < my0) + (b.w < my0);
+                        lt1 += (a.x < my1) + (a.y < my1) + (a.z < my1) + (a.w < my1) + (b.x < my1) + (b.y < my1) + (b.z < my1) + (b.w < my1);
+                    }
+                } else {
+                    for (int j = 0; j < len / 4; j += 2) {
+                        const uint4 a = p4[j], b = p4[j + 1];
+                        lt0 += (a.x < my0) + (a.y < my0) + (a.z < my0) + (a.w < my0) + (b.x < my0) + (b.y < my0) + (b.z < my0) + (b.w < my0);
+                    }
+                }
+                for (int off = parts >> 1; off > 0; off >>= 1) { lt0 += __shfl_xor(lt0, off); lt1 += __shfl_xor(lt1, off); }
+                // equal keys share their rank: count the entries per rank (2 x u16 per word)
+                if (part == 0 && i0 < nsel) atomicAdd(reinterpret_cast<uint32_t*>(rk) + (lt0 >> 1), 1u << ((lt0 & 1) * 16));
+                if (part == 0 && i1 < nsel) atomicAdd(reinterpret_cast<uint32_t*>(rk) + (lt1 >> 1), 1u << ((lt1 & 1) * 16));
+                // ranks stay in LDS for the second half (after the barrier): pcs is free by now
+                if (part == 0 && i0 < nsel) lrank[i0] = static_cast<uint16_t>(lt0);
+                if (part == 0 && i1 < nsel) lrank[i1] = static_cast<uint16_t>(lt1);
+            }
+            __syncthreads();
+            for (int i = tid; i < nsel; i += nthreads) {
+                const int lt = lrank[i];
+                const uint64_t e = ht[ulist[i]];
+                const int32_t id = static_cast<int32_t>(e >> 32);
+                if (rk[lt] == 1) {
+                    if (lt < nout) {
+                        prm.out_ids[qi * prm.out_cap + lt] = id;
+                        if (prm.out_score) prm.out_score[qi * prm.out_cap + lt] = static_cast<int32_t>(static_cast<uint32_t>(e) >> kBucketBits);
+                    }
+                } else {   // shares (score, bucket) with another entry: settled below by insertion sequence
+                    const int c = atomicAdd(&s_ncoll, 1);
+                    if (c < kLzCollMax) { c_elem[c] = i; c_lt[c] = lt; c_id[c] = id; c_seq[c] = 0x7FFFFFFF; }
+                }
+            }
+            __syncthreads();
+            LZ_STAMP(5);
+            const int ncoll = s_ncoll;
+            if (tid == 0 && prm.dbg && qi == blockIdx.x) { prm.dbg[blockIdx.x * 16 + 13] = ncoll; prm.dbg[blockIdx.x * 16 + 15] = nsel; prm.dbg[blockIdx.x * 16 + 14] = dbg_outer | (dbg_inner << 8) | (dbg_reload << 16) | (static_cast<long long>(dbg_nitb) << 24); }
+            if (ncoll > kLzCollMax) {
+                overflow = true;
+            } else if (ncoll > 0) {
+                // ---- 4. reference insertion sequence of the colliding entries: one (entry, table) pair per thread ----
+                for (int t = tid; t < ncoll * TD; t += nthreads) {
+                    const int c = t / TD, td = t - c * TD;
+                    const int32_t idx = prm.inv[static_cast<int64_t>(td) * prm.n_ids + c_id[c]];
+                    if (idx < 0) continue;
+                    for (int step = 0; step < P; step++) {
+                        const int4 e = plist[td * P + step];
+                        if (e.x >= 0 && idx >= e.z && idx < e.z + e.w) { atomicMin(&c_seq[c], (td * P + step) * S + (idx - e.z)); break; }
+                    }
+                }
+                __syncthreads();
+                for (int c = tid; c < ncoll; c += nthreads) {
+                    const uint32_t my = pre[c_elem[c]];
+                    const int myseq = c_seq[c];
+                    int rank = c_lt[c];
+                    for (int c2 = 0; c2 < ncoll; c2++) rank += (pre[c_elem[c2]] == my) && (c_seq[c2] < myseq);
+                    if (rank < nout) {
+                        prm.out_ids[qi * prm.out_cap + rank] = c_id[c];
+                        if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = static_cast<int32_t>(my >> kBucketBits);
+                    }
+                }
+            }
+            if (!overflow && tid == 0) prm.out_count[qi] = nout;
+        }
+        if (overflow && tid == 0) prm.ovf_list[atomicAdd(prm.ovf_count, 1)] = static_cast<int32_t>(qi);
+        __syncthreads();
+        LZ_STAMP(6);
+        // ---- clear exactly the slots this query used ---------------------------------------------------------------
+        const int used = min(s_u, kLzEntries);
+        for (int i = tid; i < used; i += nthreads) ht[ulist[i]] = kLzEmpty;
+        __syncthreads();
+        LZ_STAMP(7);
+    }
+#undef LZ_STAMP
+#undef LZ_FOR_TUPLES
+#undef LZ_INSERT
+}
+
+}  // namespace fspann

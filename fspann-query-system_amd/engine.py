@@ -184,10 +184,20 @@ class FspannContext:
     def effective_probes(self, probe_override=-1):
         return self.L.fspann_effective_probes(self._h, probe_override)
 
+    def set_route_mode(self, mode):
+        """0 auto, 1 full select only, 2 bounded select whenever legal (identical results)."""
+        N.check(self.L.fspann_set_route_mode(self._h, int(mode)))
+
+    def last_route_info(self):
+        import ctypes as C
+        lazy, ovf = C.c_int(0), C.c_int(0)
+        N.check(self.L.fspann_last_route_info(self._h, C.byref(lazy), C.byref(ovf)))
+        return dict(lazy=bool(lazy.value), overflowed=int(ovf.value))
+
     def route_max_candidates(self, probe_override=-1):
         return int(self.L.fspann_route_max_candidates(self._h, probe_override))
 
-    def route(self, codes, probe_override=-1, limit=N.INT32_MAX, cap=None):
+    def route(self, codes, probe_override=-1, limit=N.INT32_MAX, cap=None, counters=True):
         if codes is None:
             raise N.FspannStateError("MSANNP violation: QueryToken missing BitSet codes")
         codes = _c(codes, np.uint64).reshape(-1, self.TD, self.W)
@@ -200,7 +210,9 @@ class FspannContext:
         kept = np.zeros(nq, np.int32)
         raw = np.zeros(nq, np.int32)
         N.check(self.L.fspann_route(self._h, nq, _p(codes), probe_override, min(limit, N.INT32_MAX), cap, _p(ids),
-                                    _p(score), _p(count), _p(kept), _p(raw)))
+                                    _p(score), _p(count), _p(kept) if counters else None, _p(raw) if counters else None))
+        if not counters:   # lastCandKept / rawSeen not requested: the bounded select may run
+            return dict(ids=ids, score=score, count=count)
         return dict(ids=ids, score=score, count=count, kept=kept, raw_seen=raw)
 
     # -- Refine ----------------------------------------------------------------------

@@ -156,6 +156,12 @@ int fspann_route_dev(fspann_ctx* ctx, int64_t nq, const uint64_t* codes_dev, int
 /* Worst-case entries per query for (probes): min(T*D*probes*block_size, HARD_CAP + block_size - 1). */
 int64_t fspann_route_max_candidates(fspann_ctx* ctx, int probe_override);
 int fspann_effective_probes(fspann_ctx* ctx, int probe_override); /* PIS:880-888 */
+/* Select path of fspann_route: 0 = auto, 1 = always the full select, 2 = the bounded select whenever it is legal
+ * (limit <= 512, kept/raw_seen not requested, HARD_CAP and HashMap resize out of reach).  The bounded select reads
+ * only the probed partitions with the smallest Hamming distances; every mode returns the identical list.        */
+int fspann_set_route_mode(fspann_ctx* ctx, int mode);
+/* Diagnostics: which select the last route call ran and how many queries the bounded select handed back. */
+int fspann_last_route_info(fspann_ctx* ctx, int* lazy, int* overflowed);
 
 /* ---- Refine: QSI stage B (distance part) + stage C ------------------------------------
  * Replaces QSI.l2 (QSI:364-372), isValid (:407-413), the stable sort + top-K (:298-316).

@@ -15,6 +15,8 @@ from conftest import make_scene
 
 pytestmark = pytest.mark.gpu
 
+LAZY_RUNS = []   # last_route_info() of every bounded-select attempt made by check_route
+
 
 def ctx_for(pkg, sc, java_hash=None, **over):
     p = dict(sc["params"])
@@ -53,6 +55,17 @@ def check_route(pkg, sc, nq=16, probes=-1, limits=(None,), java_hash=None, impor
                 assert res["count"][i] == n
                 assert np.array_equal(res["ids"][i, :n], ids[i, :n]), (lim, i)
                 assert np.array_equal(res["score"][i, :n], score[i, :n]), (lim, i)
+            if lim and lim <= 512:
+                # the bounded select (no counters requested): same first `lim` entries wherever it is legal
+                ctx.set_route_mode(2)
+                res2 = ctx.route(codes, probe_override=probes, limit=lim, counters=False)
+                ctx.set_route_mode(0)
+                LAZY_RUNS.append(ctx.last_route_info())
+                assert np.array_equal(res2["count"], res["count"]), lim
+                for i in range(nq):
+                    n = res["count"][i]
+                    assert np.array_equal(res2["ids"][i, :n], ids[i, :n]), ("bounded", lim, i)
+                    assert np.array_equal(res2["score"][i, :n], score[i, :n]), ("bounded", lim, i)
     return count, raw
 
 
@@ -158,3 +171,59 @@ def test_imported_index_equals_native_build(pkg, oracle):
 def test_batch_larger_than_grid(pkg, oracle):
     sc = make_scene(oracle, n=3000, d=8, T=2, D=2, m=8, lam=2, B=32, seed=81)
     check_route(pkg, sc, nq=1500, limits=(32,))
+
+
+def _rehash(sc, jh):
+    o = sc["oracle"]
+    o.set_id_meta(sc["params"]["n"], jh, None)
+    o.build_index(sc["X64"])       # GreedyPartitioner's input order is a HashMap iteration: it depends on the hashes
+
+
+def test_bounded_select_bucket_collisions(pkg, oracle):
+    """Survivors that share (score, HashMap bucket) are ordered by the reference's first insertion, recomputed from
+    the inverse id map.  (<= 6 ids per hash value: the reference HashMap does not treeify, the order stays modelled.)"""
+    n = 30000
+    jh = (np.arange(n) % 5000).astype(np.int32)
+    for seed, clustered in ((21, False), (22, True)):
+        sc = make_scene(oracle, n=n, d=16, T=8, D=1, m=12, lam=2, B=256, seed=seed, clustered=clustered)
+        sc["params"]["clustered"] = clustered
+        _rehash(sc, jh)
+        before = len(LAZY_RUNS)
+        check_route(pkg, sc, nq=24, limits=(256, 100, 17), java_hash=jh)
+        assert all(r["lazy"] for r in LAZY_RUNS[before:])
+
+
+def test_bounded_select_degenerate_hash_hands_back(pkg, oracle):
+    """Every survivor in the same few buckets: more collisions than the bounded select settles itself -> the full
+    select redoes those queries.  (The reference HashMap would treeify here, so the oracle has no order to offer:
+    the two product paths are compared with each other.)"""
+    n = 30000
+    sc = make_scene(oracle, n=n, d=16, T=8, D=1, m=12, lam=2, B=256, seed=24)
+    codes = sc["oracle"].encode(sc["rng"].standard_normal((24, 16)))
+    with ctx_for(pkg, sc, java_hash=(np.arange(n) % 5).astype(np.int32)) as ctx:
+        ctx.build_index(sc["X"])
+        full = ctx.route(codes, limit=256)
+        ctx.set_route_mode(2)
+        lazy = ctx.route(codes, limit=256, counters=False)
+        info = ctx.last_route_info()
+    assert info["lazy"] and info["overflowed"] == 24
+    assert np.array_equal(lazy["count"], full["count"])
+    assert np.array_equal(lazy["ids"], full["ids"]) and np.array_equal(lazy["score"], full["score"])
+
+
+def test_bounded_select_hands_back_large_queries(pkg, oracle, monkeypatch):
+    """Queries whose entries exceed what the bounded select may hold are redone by the full select."""
+    sc = make_scene(oracle, n=40000, d=16, T=10, D=1, m=12, lam=2, B=256, seed=23)
+    monkeypatch.setenv("FSPANN_ROUTE_LAZY_CAP", "258")     # limit + 2: a cut that overshoots by a few ids no longer fits
+    before = len(LAZY_RUNS)
+    check_route(pkg, sc, nq=40, limits=(256,))
+    assert LAZY_RUNS[before]["lazy"] and 0 < LAZY_RUNS[before]["overflowed"] <= 40
+    monkeypatch.setenv("FSPANN_ROUTE_LAZY_CAP", "8")
+    check_route(pkg, sc, nq=40, limits=(256, 5))
+    assert LAZY_RUNS[-1]["overflowed"] > 0
+
+
+def test_zz_bounded_select_was_exercised():
+    """The scenes above must have driven the bounded select itself, and its hand-back to the full select."""
+    assert sum(1 for r in LAZY_RUNS if r["lazy"]) >= 10
+    assert any(r["lazy"] and r["overflowed"] == 0 for r in LAZY_RUNS)
