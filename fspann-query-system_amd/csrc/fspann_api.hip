@@ -93,16 +93,24 @@ int upload_index(fspann_ctx* c) {
     FSP_HIP(hipMemcpy(c->d_rep, rep.data(), rep.size() * 8, hipMemcpyHostToDevice));
     if (!off.empty()) FSP_HIP(hipMemcpy(c->d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     FSP_HIP(hipMemcpy(c->d_ids, idv.data(), idv.size() * 4, hipMemcpyHostToDevice));
-    // inverse id map for the bounded select: inv[td][id] = position of id in table td's id list.  A table that holds
-    // an id twice (never produced by PIS.insert, but importable) cannot be inverted: the bounded select stays off.
-    free_devt(c->d_inv);
-    if (c->n_ids > 0 && static_cast<int64_t>(TD) * c->n_ids < (1LL << 33)) {
+    // For the bounded select (route_lazy.hip.h):
+    //   inv[td][id]  position of id in table td's id list (a table holding an id twice cannot be inverted: select stays off)
+    //   ids_bk       every partition's ids once more, as (id << 32 | bucket field at the initial HashMap capacity),
+    //                sorted by bucket within the partition, so the ids with the smallest buckets are a prefix
+    free_devt(c->d_inv); free_devt(c->d_ids_bk);
+    c->bk_epoch = -1;
+    if (c->n_ids > 0 && static_cast<int64_t>(TD) * c->n_ids < (1LL << 33) && c->cap0 <= (1 << kBucketBits) && c->cfg.block_size <= 4096) {
         std::vector<int32_t> inv(static_cast<size_t>(TD) * static_cast<size_t>(c->n_ids), -1);
+        std::vector<uint64_t> bk(static_cast<size_t>(std::max<int64_t>(ids, 1)));
+        const int capbits = 31 - __builtin_clz(static_cast<unsigned>(c->cap0));
+        const uint32_t bmask = static_cast<uint32_t>(c->cap0 - 1);
+        const int bshift = kBucketBits - capbits;
         std::atomic<bool> ok{true};
         std::vector<std::thread> th;
         const int nth = std::max(1, std::min<int>(TD, static_cast<int>(std::thread::hardware_concurrency())));
         for (int w = 0; w < nth; w++)
             th.emplace_back([&, w] {
+                std::vector<uint64_t> tmp;
                 for (int td = w; td < TD; td += nth) {
                     int32_t* row = inv.data() + static_cast<size_t>(td) * static_cast<size_t>(c->n_ids);
                     const std::vector<int32_t>& v = c->h_ids[td];
@@ -110,12 +118,30 @@ int upload_index(fspann_ctx* c) {
                         if (v[i] < 0 || v[i] >= c->n_ids || row[v[i]] != -1) { ok = false; break; }
                         row[v[i]] = static_cast<int32_t>(i);
                     }
+                    if (!ok) return;
+                    const RouteTable& t = c->h_tables[td];
+                    for (int p = 0; p < t.nparts; p++) {
+                        const int64_t b0 = c->h_off[td][p], b1 = c->h_off[td][p + 1];
+                        tmp.clear();
+                        for (int64_t i = b0; i < b1; i++) {
+                            uint32_t h = static_cast<uint32_t>(c->h_java_hash[static_cast<size_t>(v[i])]);
+                            h ^= (h >> 16);   // HashMap.hash()
+                            const uint64_t bf = static_cast<uint64_t>((h & bmask) << bshift);
+                            tmp.push_back((bf << 44) | (static_cast<uint64_t>(i - b0) << 32) | static_cast<uint32_t>(v[i]));   // sort key: bucket, position
+                        }
+                        std::sort(tmp.begin(), tmp.end());
+                        for (size_t j = 0; j < tmp.size(); j++)
+                            bk[static_cast<size_t>(t.ids_base + b0) + j] = (static_cast<uint64_t>(static_cast<uint32_t>(tmp[j])) << 32) | (tmp[j] >> 44);
+                    }
                 }
             });
         for (auto& t : th) t.join();
         if (ok) {
             FSP_HIP(hipMalloc(&c->d_inv, inv.size() * 4));
             FSP_HIP(hipMemcpy(c->d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
+            FSP_HIP(hipMalloc(&c->d_ids_bk, bk.size() * 8));
+            FSP_HIP(hipMemcpy(c->d_ids_bk, bk.data(), bk.size() * 8, hipMemcpyHostToDevice));
+            c->bk_epoch = c->meta_epoch;
         }
     }
     c->dev_index_dirty = false;
@@ -243,7 +269,7 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     // ---- bounded select: legal when the first `limit` entries do not depend on how many ids exist ----------------
     pl.lazy = 0;
     const bool cap_fixed = java_final_cap_host(c->cap0, mt) == c->cap0;       // HashMap never resizes
-    const bool legal = c->d_inv && !pl.need_cap && cap_fixed && !want_counters && limit <= 512 && pl.lds_mode;
+    const bool legal = c->d_inv && c->d_ids_bk && c->bk_epoch == c->meta_epoch && !pl.need_cap && cap_fixed && !want_counters && limit <= 512 && pl.lds_mode;
     if (legal && c->route_mode != 1 && (c->route_mode == 2 || static_cast<int64_t>(limit) * 4 <= mt)) {
         const char* ce = getenv("FSPANN_ROUTE_LAZY_CAP");   // tests: distinct ids one query may hold before it is handed back
         const int cap_env = ce ? atoi(ce) : 0;
@@ -392,7 +418,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
     free_dev(c->d_store);
-    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_devt(c->d_inv);
+    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -575,7 +601,8 @@ int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, c
             FSP_HIP(hipMemcpy(c->d_deleted_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    if (n_ids != c->n_ids) { free_devt(c->d_inv); c->dev_index_dirty = true; }   // the inverse id map is [TD][n_ids]
+    c->meta_epoch++;             // d_inv / d_ids_bk were built for the previous hashes: the bounded select waits for the next finalize
+    c->dev_index_dirty = true;
     c->n_ids = n_ids;
     return FSPANN_OK;
 }
@@ -784,7 +811,7 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     p.out_cap = cap; p.out_ids = ids_dev; p.out_score = score_dev; p.out_count = count_dev; p.out_kept = kept_dev; p.out_raw = raw_seen_dev;
     if (pl.lazy) {
         if ((rc = ensure(c, c->ws_ovf, static_cast<size_t>(nq) * 4 + 256))) return rc;
-        p.inv = c->d_inv; p.n_ids = c->n_ids; p.lazy_cap = pl.lazy_cap; p.lz_ht_size = pl.lz_ht_size;
+        p.inv = c->d_inv; p.ids_bk = c->d_ids_bk; p.n_ids = c->n_ids; p.lazy_cap = pl.lazy_cap; p.lz_ht_size = pl.lz_ht_size;
         p.lz_ht_shift = 32 - __builtin_ctz(pl.lz_ht_size);
         p.ovf_count = static_cast<int32_t*>(c->ws_ovf.p);
         p.ovf_list = p.ovf_count + 64;
@@ -824,7 +851,7 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
         FSP_HIP(hipGetLastError());
         // queries the bounded select handed back (none, normally): the full select over the overflow list
         p.qcount = p.ovf_count; p.qlist = p.ovf_list;
-        pl.grid = std::min(pl.grid, 128);
+        pl.grid = std::min(pl.grid, 32);    // normally nothing to do: keep the launch small
     }
     if (pl.lds_mode) { if (pl.threads == 1024) FSP_LAUNCH_SEL(true, 1024); else FSP_LAUNCH_SEL(true, 512); }
     else { if (pl.threads == 1024) FSP_LAUNCH_SEL(false, 1024); else FSP_LAUNCH_SEL(false, 512); }

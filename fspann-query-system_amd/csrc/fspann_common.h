@@ -103,6 +103,8 @@ struct fspann_ctx {
     int32_t* d_off = nullptr;     // per table nparts+1 entries, relative to ids_base
     int32_t* d_ids = nullptr;
     int32_t* d_inv = nullptr;        // [TD][n_ids] inverse id map for the bounded select (null: a table holds an id twice)
+    uint64_t* d_ids_bk = nullptr;    // per partition: (id << 32 | bucket field) sorted by bucket, for the bounded select
+    int meta_epoch = 0, bk_epoch = -1;  // d_ids_bk / d_inv are valid for the id metadata of bk_epoch
     int route_mode = 0;              // 0 auto, 1 always route_select_kernel, 2 bounded select whenever its preconditions hold
     fspann::DevBuf ws_ovf;
     int last_route_lazy = 0;         // 1 if the last fspann_route[_dev] ran the bounded select

@@ -68,6 +68,7 @@ struct RouteParams {
     int decimal_ids;               // 1: ids are Long.toString(handle) -> hash computed arithmetically
     // bounded ("lazy") select, route_lazy.hip.h
     const int32_t* inv;            // [TD][n_ids] position of an id in table td's id list (-1 = absent)
+    const uint64_t* ids_bk;        // ids of every partition as (id << 32 | bucket field), bucket-sorted within the partition
     int64_t n_ids;
     int lazy_cap;                  // tuples one query may insert before it is handed to route_select_kernel
     int lz_ht_size, lz_ht_shift;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
     int32_t* c_id = bins + 2 * kLzCollMax;
     int32_t* c_seq = bins + 3 * kLzCollMax;
 
-    __shared__ int s_u, s_R, s_ncoll, s_bad, s_b, s_cnt;
+    __shared__ int s_u, s_R, s_ncoll, s_bad, s_b, s_cnt, s_short;
     constexpr uint32_t ht_mask = kLzHtSize - 1;
     constexpr int ht_shift = 32 - 11;
     static_assert(kLzHtSize == 2048, "ht_shift");
@@ -115,15 +115,6 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
     for (int i = tid; i < kLzHtSize; i += nthreads) ht[i] = kLzEmpty;
 
-    // HashMap geometry is fixed (no resize can happen, see preconditions)
-    const int capbits = 31 - __clz(prm.cap0);
-    const uint32_t bmask = static_cast<uint32_t>(prm.cap0 - 1);
-    const int bshift = kBucketBits - capbits;
-    auto bucket_field = [&](int32_t id) -> uint32_t {
-        uint32_t h = prm.decimal_ids ? decimal_string_hash_dev(static_cast<uint32_t>(id)) : static_cast<uint32_t>(prm.java_hash[id]);
-        h ^= (h >> 16);                              // HashMap.hash()
-        return (h & bmask) << bshift;
-    };
     // is `id` already an entry?  (an entry of an earlier level: its score is lower, this occurrence changes nothing)
     auto present = [&](int32_t id) -> bool {
         uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> ht_shift;
@@ -157,28 +148,30 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
     };
 
 #define LZ_STAMP(i) do { if (prm.dbg && tid == 0 && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
-// Every live tuple of the sorted probes [RA, RB): BODY sees `id` (>= 0 when live and not deleted, else -1) and `sc`;
+// Every live tuple of the sorted probes [RA, RB): BODY sees `id` (>= 0 when live and not deleted, else -1), its bucket
+// field `bf` and the partition's distance `sc`;
 // kLzStageU partitions are in flight per wave (one coalesced 256-byte id row each).  Trip counts are wave-uniform.
 #define LZ_FOR_TUPLES(RA, RB, BODY)                                                                                   \
     do {                                                                                                              \
         const int nit_ = ((RB) - (RA)) * SP;                                                                          \
         for (int it0_ = wave; it0_ < nit_; it0_ += nwv * kLzStageU) {                                                 \
-            int32_t idv_[kLzStageU];                                                                                  \
+            uint64_t entv_[kLzStageU];                                                                                \
             int scv_[kLzStageU];                                                                                      \
             _Pragma("unroll") for (int v_ = 0; v_ < kLzStageU; v_++) {                                                \
                 const int it_ = it0_ + v_ * nwv;                                                                      \
-                idv_[v_] = -1; scv_[v_] = 0;                                                                          \
+                entv_[v_] = kLzEmpty; scv_[v_] = 0;                                                                   \
                 if (it_ < nit_) {                                                                                     \
                     const int rr_ = (RA) + it_ / SP, pos_ = (it_ % SP) * 64 + lane;                                   \
                     const int pi_ = ord[rr_];                                                                         \
                     const int4 pr_ = plist[pi_];                                                                      \
                     scv_[v_] = pr_.y;                                                                                 \
-                    if (pos_ < pr_.w) idv_[v_] = prm.ids[ids_base[pi_ / P] + pr_.z + pos_];                           \
+                    if (pos_ < pr_.w) entv_[v_] = prm.ids_bk[ids_base[pi_ / P] + pr_.z + pos_];                       \
                 }                                                                                                     \
             }                                                                                                         \
             _Pragma("unroll") for (int v_ = 0; v_ < kLzStageU; v_++) {                                                \
                 if (it0_ + v_ * nwv >= nit_) continue;                                                                \
-                int32_t id = idv_[v_];                                                                                \
+                int32_t id = static_cast<int32_t>(entv_[v_] >> 32);   /* -1 when no tuple */                           \
+                const uint32_t bf = static_cast<uint32_t>(entv_[v_]); (void)bf;                                       \
                 const int sc = scv_[v_]; (void)sc;                                                                    \
                 if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1; /* PIS:739 */ \
                 BODY                                                                                                  \
@@ -211,7 +204,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             plist[i] = e;
             pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
         }
-        if (tid == 0) { s_u = 0; s_R = TP; s_ncoll = 0; s_bad = 0; pkv[TP] = make_uint2(0xFFFFFFFFu, 0u); }
+        if (tid == 0) { s_u = 0; s_R = TP; s_ncoll = 0; s_bad = 0; s_short = 0; pkv[TP] = make_uint2(0xFFFFFFFFu, 0u); }
         __syncthreads();
         LZ_STAMP(1);
         // ---- 1. order the probed partitions by (distance, Java order); prefix sums of their sizes ----------------
@@ -238,6 +231,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
         bool overflow = false;
         int r0 = 0, u = 0;
         int dbg_outer = 0, dbg_inner = 0, dbg_reload = 0, dbg_nitb = 0;
+        bool force_full = false;
         // ---- 2. walk the distance levels ---------------------------------------------------------------------------
         while (r0 < R && u < prm.limit) {
             const int need = prm.limit - u;
@@ -253,22 +247,42 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
                 if (bb & ~bf) { r_nofit = c0 + __ffsll(static_cast<long long>(bb & ~bf)) - 1; break; }   // later ones do not fit either
             }
             const int rb0 = r_fit, rb1 = (r_fit < R) ? r_nofit : R;   // [rb0, rb1): the level that can cross (may be empty)
-            // one global round trip for both: the ids of the crossing level are requested now and stay in registers
-            // (at most kLzKeep partitions per wave; larger levels are re-read when needed)
-            const int nitB = (rb1 - rb0) * SP;
+            // one global round trip for both: the crossing level is requested now and stays in registers.  Its partitions
+            // are bucket-sorted (ids_bk), and only about need/tuples of the level can be selected, so a PREFIX of L entries
+            // per partition is read: twice the expected share + 8 (checked after the cut: a partition whose L-th entry
+            // is still at or below the cut was read short -> the level is redone with whole partitions).
+            const int npB = rb1 - rb0;
+            int L = 64;
+            if (npB > 0 && SP == 1 && !force_full) {
+                const int tuplesB = max(pcs[rb1] - pcs[rb0], 1);
+                const int want = (2 * 64 * need) / tuplesB + 8;
+                L = (want <= 8) ? 8 : (want <= 16) ? 16 : (want <= 32) ? 32 : 64;
+            }
+            const int Lsh = 31 - __clz(L);                      // log2(L)
+            const int G = 64 >> Lsh;                            // partitions per wave trip
+            const int nitB = (L == 64) ? npB * SP : (npB + G - 1) / G;
             const bool keep = (nitB > 0) && (nitB <= nwv * kLzKeep);
             dbg_outer++; dbg_reload += (nitB > 0 && !keep); dbg_nitb = max(dbg_nitb, nitB);
             int32_t idr[kLzKeep];
-            uint32_t bfr[kLzKeep];
+            uint32_t bfr[kLzKeep];   // bucket field; bit 31: last entry of a prefix that does not cover its partition
             if (keep) {
 #pragma unroll
                 for (int k = 0; k < kLzKeep; k++) {
                     const int it = wave + k * nwv;
-                    idr[k] = -1;
+                    idr[k] = -1; bfr[k] = 0;
                     if (it < nitB) {
-                        const int pi = ord[rb0 + it / SP], pos = (it % SP) * 64 + lane;
-                        const int4 pr = plist[pi];
-                        if (pos < pr.w) idr[k] = prm.ids[ids_base[pi / P] + pr.z + pos];
+                        int pidx, pos;
+                        if (L == 64) { pidx = it / SP; pos = (it % SP) * 64 + lane; }
+                        else { pidx = it * G + (lane >> Lsh); pos = lane & (L - 1); }
+                        if (pidx < npB) {
+                            const int pi = ord[rb0 + pidx];
+                            const int4 pr = plist[pi];
+                            if (pos < pr.w) {
+                                const uint64_t ent = prm.ids_bk[ids_base[pi / P] + pr.z + pos];
+                                idr[k] = static_cast<int32_t>(ent >> 32);
+                                bfr[k] = static_cast<uint32_t>(ent) | ((L < 64 && pos == L - 1 && pr.w > L) ? 0x80000000u : 0u);
+                            }
+                        }
                     }
                 }
             }
@@ -276,9 +290,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             if (r_fit > r0) {
                 // a. whole levels, at most `need` tuples: u stays <= limit
                 LZ_FOR_TUPLES(r0, r_fit, {
-                    uint32_t low = 0;
-                    if (id >= 0) low = (static_cast<uint32_t>(sc) << kBucketBits) | bucket_field(id);
-                    LZ_INSERT(id >= 0, low);
+                    LZ_INSERT(id >= 0, (static_cast<uint32_t>(sc) << kBucketBits) | bf);
                 });
             }
             __syncthreads();
@@ -297,22 +309,21 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
                 for (int k = 0; k < kLzKeep; k++) {
                     int32_t id = idr[k];
                     if (id >= 0 && prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) id = -1;   // PIS:739
-                    bfr[k] = 0;
                     if (id >= 0) {
-                        bfr[k] = bucket_field(id);
                         if (present(id)) id = -1;                              // entry of an earlier level: nothing to do
-                        else atomicAdd(&bins[bfr[k] >> (kBucketBits - 10)], 1);
+                        else atomicAdd(&bins[(bfr[k] & 0xFFFFFu) >> (kBucketBits - 10)], 1);
                     }
                     idr[k] = id;
                 }
             } else {
                 LZ_FOR_TUPLES(rb0, rb1, {
-                    if (id >= 0 && !present(id)) atomicAdd(&bins[bucket_field(id) >> (kBucketBits - 10)], 1);
+                    if (id >= 0 && !present(id)) atomicAdd(&bins[bf >> (kBucketBits - 10)], 1);
                 });
             }
             __syncthreads();
             LZ_STAMP(10);
             int lo = 0;
+            bool redo_full = false;
             while (true) {
                 if (wave == 0) {
                     int before = 0;
@@ -325,16 +336,25 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
                 dbg_inner++;
                 const int b = s_b;
                 if (u + s_cnt > prm.lazy_cap) { overflow = true; break; }   // lazy_cap <= kLzEntries
+                if (keep && L < 64) {
+                    bool shortp = false;
+#pragma unroll
+                    for (int k = 0; k < kLzKeep; k++)
+                        shortp = shortp || ((bfr[k] & 0x80000000u) && static_cast<int>((bfr[k] & 0xFFFFFu) >> (kBucketBits - 10)) <= b);
+                    if (__any(shortp) && lane == 0) s_short = 1;
+                    __syncthreads();
+                    if (s_short) { redo_full = true; break; }
+                }
                 if (keep) {
                     // all inserts of this wave first, then ONE LDS atomic for the wave's new entries.  An id in range is
                     // finished either way (created, or already an entry): idr = -2 marks "created", bfr then holds the slot
                     int total = 0;
 #pragma unroll
                     for (int k = 0; k < kLzKeep; k++) {
-                        const int bin = static_cast<int>(bfr[k] >> (kBucketBits - 10));
+                        const int bin = static_cast<int>((bfr[k] & 0xFFFFFu) >> (kBucketBits - 10));
                         if (idr[k] >= 0 && bin >= lo && bin <= b) {
                             uint32_t slot = 0;
-                            const bool c = insert(idr[k], sc_hi | bfr[k], &slot);
+                            const bool c = insert(idr[k], sc_hi | (bfr[k] & 0xFFFFFu), &slot);
                             idr[k] = c ? -2 : -1;
                             if (c) bfr[k] = slot;
                         }
@@ -356,14 +376,8 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
                     }
                 } else {
                     LZ_FOR_TUPLES(rb0, rb1, {
-                        uint32_t bfld = 0;
-                        bool in = false;
-                        if (id >= 0) {
-                            bfld = bucket_field(id);
-                            const int bin = static_cast<int>(bfld >> (kBucketBits - 10));
-                            in = (bin >= lo && bin <= b);
-                        }
-                        LZ_INSERT(in, sc_hi | bfld);
+                        const int bin = static_cast<int>(bf >> (kBucketBits - 10));
+                        LZ_INSERT(id >= 0 && bin >= lo && bin <= b, sc_hi | bf);
                     });
                 }
                 __syncthreads();
@@ -375,6 +389,15 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
                 __syncthreads();                     // s_u / s_b have been read by everyone before they move again
             }
             if (overflow) break;
+            if (redo_full) {                          // nothing of this level was inserted yet: same level again, whole partitions
+                r0 = rb0;
+                force_full = true;
+                __syncthreads();
+                if (tid == 0) s_short = 0;
+                __syncthreads();
+                continue;
+            }
+            force_full = false;
             r0 = rb1;
             __syncthreads();
         }
@@ -384,41 +407,34 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
         if (nsel > kLzSortMax) overflow = true;
         if (!overflow) {
             const int nout = min(nsel, prm.limit);
-            // element i is ranked by `parts` cooperating lanes, each over a slice of the keys; with more entries than
-            // lanes a lane carries two elements through the same scan
-            int parts = 1;
-            while (parts < 16 && nsel * parts * 2 <= nthreads) parts <<= 1;
-            const int len = (((nsel + parts - 1) / parts) + 7) & ~7;   // slice length, multiple of 8
-            const int padded = parts * len;                            // <= kLzSortMax + 7 < 1024
-            for (int i = tid; i < padded; i += nthreads) pre[i] = (i < nsel) ? static_cast<uint32_t>(ht[ulist[i]]) : 0xFFFFFFFFu;
+            // element i is ranked by `parts` cooperating lanes, each over a slice of the keys.  Rounds: as many elements as
+            // lanes allow, then the few left over with more lanes each (257 entries = 256 with one lane + 1 with 16).
+            for (int i = tid; i < 1024; i += nthreads) pre[i] = (i < nsel) ? static_cast<uint32_t>(ht[ulist[i]]) : 0xFFFFFFFFu;
             for (int i = tid; i < 512; i += nthreads) reinterpret_cast<uint32_t*>(rk)[i] = 0u;
             __syncthreads();
             LZ_STAMP(4);
-            const int per_pass = nthreads / parts;
-            for (int base = 0; base < nsel; base += 2 * per_pass) {
-                const int i0 = base + tid / parts, i1 = i0 + per_pass, part = tid % parts;
-                const uint32_t my0 = (i0 < nsel) ? pre[i0] : 0u, my1 = (i1 < nsel) ? pre[i1] : 0u;
-                int lt0 = 0, lt1 = 0;
+            for (int e0 = 0; e0 < nsel;) {
+                const int rem = nsel - e0;
+                int parts = 1;
+                while (parts < 16 && rem * parts * 2 <= nthreads) parts <<= 1;
+                const int cnt = min(rem, nthreads / parts);
+                const int len = (((nsel + parts - 1) / parts) + 7) & ~7;   // slice length, multiple of 8; parts * len <= 1024
+                const int i = e0 + tid / parts, part = tid % parts;
+                const bool act = (tid / parts) < cnt;
+                const uint32_t my = act ? pre[i] : 0u;
+                int lt = 0;
                 const uint4* p4 = reinterpret_cast<const uint4*>(pre + part * len);
-                if (base + per_pass < nsel) {        // block-uniform: second elements exist
-                    for (int j = 0; j < len / 4; j += 2) {
-                        const uint4 a = p4[j], b = p4[j + 1];
-                        lt0 += (a.x < my0) + (a.y < my0) + (a.z < my0) + (a.w < my0) + (b.x < my0) + (b.y < my0) + (b.z < my0) + (b.w < my0);
-                        lt1 += (a.x < my1) + (a.y < my1) + (a.z < my1) + (a.w < my1) + (b.x < my1) + (b.y < my1) + (b.z < my1) + (b.w < my1);
-                    }
-                } else {
-                    for (int j = 0; j < len / 4; j += 2) {
-                        const uint4 a = p4[j], b = p4[j + 1];
-                        lt0 += (a.x < my0) + (a.y < my0) + (a.z < my0) + (a.w < my0) + (b.x < my0) + (b.y < my0) + (b.z < my0) + (b.w < my0);
-                    }
+                for (int j = 0; j < len / 4; j += 2) {
+                    const uint4 a = p4[j], b = p4[j + 1];
+                    lt += (a.x < my) + (a.y < my) + (a.z < my) + (a.w < my) + (b.x < my) + (b.y < my) + (b.z < my) + (b.w < my);
                 }
-                for (int off = parts >> 1; off > 0; off >>= 1) { lt0 += __shfl_xor(lt0, off); lt1 += __shfl_xor(lt1, off); }
-                // equal keys share their rank: count the entries per rank (2 x u16 per word)
-                if (part == 0 && i0 < nsel) atomicAdd(reinterpret_cast<uint32_t*>(rk) + (lt0 >> 1), 1u << ((lt0 & 1) * 16));
-                if (part == 0 && i1 < nsel) atomicAdd(reinterpret_cast<uint32_t*>(rk) + (lt1 >> 1), 1u << ((lt1 & 1) * 16));
-                // ranks stay in LDS for the second half (after the barrier): pcs is free by now
-                if (part == 0 && i0 < nsel) lrank[i0] = static_cast<uint16_t>(lt0);
-                if (part == 0 && i1 < nsel) lrank[i1] = static_cast<uint16_t>(lt1);
+                for (int off = parts >> 1; off > 0; off >>= 1) lt += __shfl_xor(lt, off);
+                if (act && part == 0) {
+                    // equal keys share their rank: count the entries per rank (2 x u16 per word)
+                    atomicAdd(reinterpret_cast<uint32_t*>(rk) + (lt >> 1), 1u << ((lt & 1) * 16));
+                    lrank[i] = static_cast<uint16_t>(lt);
+                }
+                e0 += cnt;
             }
             __syncthreads();
             for (int i = tid; i < nsel; i += nthreads) {
