@@ -3,7 +3,8 @@ package com.fspann.gpu;
 import java.nio.ByteBuffer;
 
 /**
- * JNI binding of libfspann_hip.so (include/fspann.h) — pure marshalling, one native method per C entry point.
+ * JNI binding of libfspann_hip.so (include/fspann.h) — pure marshalling, one native method per C entry point the JVM adapter uses
+ * (the device-pointer *_dev variants, index save/load and the native Setup are reached from C++/Python hosts).
  *
  * All buffers are DIRECT ByteBuffers in native byte order (the C side reads them in place; no copies on the Java
  * side).  Every method returns the C return code; {@link #check(int)} turns it into the exception class the
@@ -44,6 +45,13 @@ public final class FspannNative {
     public static native int refine(long ctx, long nq, ByteBuffer q, ByteBuffer cand, int dtype, long B,
                                     ByteBuffer candIds, ByteBuffer candCount, int k,
                                     ByteBuffer outIds, ByteBuffer outDist, ByteBuffer outCount, ByteBuffer scored);
+
+    /** Plaintext rows resident on the device (tests / trusted-HBM deployments), then stage B/C by id without a staging copy. */
+    public static native int storeSet(long ctx, long n, ByteBuffer vectors, int dtype);
+    public static native int refineStore(long ctx, long nq, ByteBuffer q, int dtype, long B, ByteBuffer candIds, ByteBuffer candCount,
+                                         int k, ByteBuffer outIds, ByteBuffer outDist, ByteBuffer outCount, ByteBuffer scored);
+    /** 0 auto, 1 full select, 2 bounded select whenever legal; route(..., kept = null, rawSeen = null) enables the bounded one. */
+    public static native int setRouteMode(long ctx, int mode);
 
     public static void check(int rc) {
         if (rc == 0) return;

@@ -84,4 +84,22 @@ JNIEXPORT jint JNICALL Java_com_fspann_gpu_FspannNative_refine(JNIEnv* env, jcla
                          static_cast<int32_t*>(addr(env, scored)));
 }
 
+// Plaintext rows resident on the device (test / trusted-HBM deployments): set once, then refine by id.
+JNIEXPORT jint JNICALL Java_com_fspann_gpu_FspannNative_storeSet(JNIEnv* env, jclass, jlong h, jlong n, jobject vectors, jint dtype) {
+    return fspann_store_set(C(h), n, addr(env, vectors), dtype);
+}
+
+JNIEXPORT jint JNICALL Java_com_fspann_gpu_FspannNative_refineStore(JNIEnv* env, jclass, jlong h, jlong nq, jobject q, jint dtype, jlong B,
+                                                                    jobject candIds, jobject candCount, jint k, jobject outIds,
+                                                                    jobject outDist, jobject outCount, jobject scored) {
+    return fspann_refine_store(C(h), nq, addr(env, q), dtype, B, static_cast<const int32_t*>(addr(env, candIds)),
+                               static_cast<const int32_t*>(addr(env, candCount)), k, static_cast<int32_t*>(addr(env, outIds)),
+                               static_cast<double*>(addr(env, outDist)), static_cast<int32_t*>(addr(env, outCount)),
+                               static_cast<int32_t*>(addr(env, scored)));
+}
+
+JNIEXPORT jint JNICALL Java_com_fspann_gpu_FspannNative_setRouteMode(JNIEnv*, jclass, jlong h, jint mode) {
+    return fspann_set_route_mode(C(h), mode);
+}
+
 }  // extern "C"
