@@ -35,7 +35,6 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
     double* __restrict__ proj, const unsigned long long* __restrict__ only_if_over, unsigned long long over_cap) {
     // fallback launch behind the MFMA path: runs only when its re-check list overflowed
     if (only_if_over && *only_if_over <= over_cap) return;
-    __shared__ double vs[QB * kEncDC];
     __shared__ int32_t Hs[QB * kEncThreads];
     __shared__ int badq[QB];
 
@@ -48,35 +47,33 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
     const int p = td0 * m + tid;
 
     if (tid < QB) badq[tid] = 0;
+    __syncthreads();
+    // NaN / Inf in a query vector (Coding.java:356-361): flagged here, the sums below simply carry the NaN
+    for (int idx = tid; idx < QB * d; idx += kEncThreads) {
+        const int qq = idx / d, i = idx - qq * d;
+        const int64_t qi = q0 + qq;
+        if (qi < nq && !(fabs(static_cast<double>(q[qi * d + i])) <= 1.79769313486231570815e+308)) atomicOr(&badq[qq], 1);
+    }
 
     double acc[QB];
 #pragma unroll
     for (int i = 0; i < QB; i++) acc[i] = 0.0;
 
-    for (int c0 = 0; c0 < d; c0 += kEncDC) {
-        const int dc = min(kEncDC, d - c0);
-        __syncthreads();
-        for (int idx = tid; idx < QB * dc; idx += kEncThreads) {
-            const int qq = idx / dc, i = idx - qq * dc;
-            const int64_t qi = q0 + qq;
-            double v = 0.0;
-            if (qi < nq) {
-                v = static_cast<double>(q[qi * d + c0 + i]);
-                if (!(fabs(v) <= 1.79769313486231570815e+308)) atomicOr(&badq[qq], 1);  // NaN or Inf
-            }
-            vs[qq * kEncDC + i] = v;
-        }
-        __syncthreads();
-        if (active) {
-            const double* ap = alphaT + static_cast<int64_t>(c0) * P + p;
-#pragma unroll 4
-            for (int i = 0; i < dc; i++) {
-                const double a = ap[static_cast<int64_t>(i) * P];
+    // The query elements are the same for every lane (one lane = one projection): their addresses are wave-uniform,
+    // so they come through the scalar cache (s_load) and feed the fp64 multiply as scalar operands — no LDS staging,
+    // no barrier in the loop.  alpha is streamed coalesced from alphaT (64 consecutive doubles per wave and dimension).
+    const TIn* qrow[QB];
 #pragma unroll
-                for (int qq = 0; qq < QB; qq++) {
-                    const double prod = vs[qq * kEncDC + i] * a;  // acc += a[i]*b[i], Coding.java:351
-                    acc[qq] = acc[qq] + prod;
-                }
+    for (int qq = 0; qq < QB; qq++) qrow[qq] = q + min(q0 + qq, nq - 1) * d;   // rows past nq: computed, never stored
+    if (active) {
+        const double* ap = alphaT + p;
+#pragma unroll 8
+        for (int i = 0; i < d; i++) {
+            const double a = ap[static_cast<int64_t>(i) * P];
+#pragma unroll
+            for (int qq = 0; qq < QB; qq++) {
+                const double prod = static_cast<double>(qrow[qq][i]) * a;  // acc += a[i]*b[i], Coding.java:351
+                acc[qq] = acc[qq] + prod;
             }
         }
     }
@@ -97,24 +94,45 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
 
     // Coding.C: bit pos = (lambda-1-i)*m + j  <-  bit i of (h_j ^ 0x80000000)
     const int bitsTotal = m * lambda;
-    const int nwords = QB * tdn * W;
-    for (int wi = tid; wi < nwords; wi += kEncThreads) {
-        const int qq = wi / (tdn * W);
-        const int rem = wi - qq * (tdn * W);
-        const int tdl = rem / W, w = rem - tdl * W;
-        const int64_t qi = q0 + qq;
-        if (qi >= nq) continue;
-        uint64_t word = 0;
-        const int pos0 = w * 64;
-        const int pos1 = min(bitsTotal, pos0 + 64);
-        for (int pos = pos0; pos < pos1; pos++) {
-            const int plane = pos / m;            // 0 .. lambda-1, MSB plane first
-            const int j = pos - plane * m;
-            const int i = lambda - 1 - plane;
-            const uint32_t hj = static_cast<uint32_t>(Hs[qq * kEncThreads + tdl * m + j]) ^ 0x80000000u;
-            word |= static_cast<uint64_t>((hj >> (i & 31)) & 1u) << (pos - pos0);
+    if ((64 % m) == 0) {
+        // m divides the wave: the m lanes of one table are adjacent, so plane i of a table's code is an m-bit field of
+        // one ballot.  Lane j < W of the group assembles word j from the lambda fields (a field never straddles words).
+        const int lane = tid & 63;
+        const int g0 = (lane / m) * m, j = lane - g0;
+        const int tdl = tid / m;
+        const uint64_t fmask = (m == 64) ? ~0ull : ((1ull << m) - 1ull);
+#pragma unroll
+        for (int qq = 0; qq < QB; qq++) {
+            const uint32_t hj = active ? (static_cast<uint32_t>(Hs[qq * kEncThreads + tid]) ^ 0x80000000u) : 0u;
+            uint64_t word = 0;
+            for (int i = 0; i < lambda; i++) {
+                const unsigned long long bm = __ballot((hj >> (i & 31)) & 1u);
+                const int pos0 = (lambda - 1 - i) * m;
+                if ((pos0 >> 6) == j) word |= ((bm >> g0) & fmask) << (pos0 & 63);
+            }
+            const int64_t qi = q0 + qq;
+            if (active && j < W && qi < nq) codes[(qi * TD + td0 + tdl) * W + j] = word;
         }
-        codes[(qi * TD + td0 + tdl) * W + w] = word;
+    } else {
+        const int nwords = QB * tdn * W;
+        for (int wi = tid; wi < nwords; wi += kEncThreads) {
+            const int qq = wi / (tdn * W);
+            const int rem = wi - qq * (tdn * W);
+            const int tdl = rem / W, w = rem - tdl * W;
+            const int64_t qi = q0 + qq;
+            if (qi >= nq) continue;
+            uint64_t word = 0;
+            const int pos0 = w * 64;
+            const int pos1 = min(bitsTotal, pos0 + 64);
+            for (int pos = pos0; pos < pos1; pos++) {
+                const int plane = pos / m;            // 0 .. lambda-1, MSB plane first
+                const int j = pos - plane * m;
+                const int i = lambda - 1 - plane;
+                const uint32_t hj = static_cast<uint32_t>(Hs[qq * kEncThreads + tdl * m + j]) ^ 0x80000000u;
+                word |= static_cast<uint64_t>((hj >> (i & 31)) & 1u) << (pos - pos0);
+            }
+            codes[(qi * TD + td0 + tdl) * W + w] = word;
+        }
     }
     if (bad && blockIdx.y == 0 && tid < QB && q0 + tid < nq) bad[q0 + tid] = badq[tid];
 }
