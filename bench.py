@@ -217,8 +217,13 @@ def main():
     evs = [[ev() for _ in range(5)] for _ in range(args.steps)]
     barrier()
     t_start = time.perf_counter()
+    # timed region: every 5th refinement-scan dispatch carries its own start/stop HIP events (kernel-attached, on the
+    # context's stream) -> roofline.  (An attached pair costs a few us of stream time, so not every dispatch gets one.)
+    TIMED_EVERY = 5
+    for c_ in ctxs[:active[0]]:
+        c_.refine_timing_begin(args.steps, TIMED_EVERY)
     for i in range(args.steps):
-        step(evs[i], ref_only=True)          # timed region: HIP events only around the refinement scan (roofline)
+        step()
     for c_ in ctxs:
         c_.sync()
     torch.cuda.synchronize()
@@ -230,7 +235,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    ref_ms_timed = float(np.mean([evs[i][3].elapsed_time(evs[i][4]) for i in range(args.steps)]))
+    rt = [c_.refine_timing_end() for c_ in ctxs[:active[0]]]
+    ref_ms_timed = sum(t for _, t in rt) / max(1, sum(n for n, _ in rt))          # kernel-attached events
+
     # ---- stage breakdown: a separate, untimed pass with an event after every stage -----------------------------
     nprof = min(args.steps, 20)
     barrier()
@@ -290,7 +297,10 @@ def main():
     kname = "refine_scan_kernel<float,float,32,true,%s>" % ("false" if dense else "true")
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5))
+                    algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5), launches=sum(n for n, _ in rt),
+                    timing="HIP start/stop events attached to every %d-th refine_scan_kernel dispatch of the timed region "
+                           "(hipExtLaunchKernel, on the context's stream)" % TIMED_EVERY,
+                    bracket_ms=round(float(st_mean[3]), 5))
 
     # Route (probe + select) is the longest stage but is bound by dependent L2 rounds and LDS atomics, not by HBM or
     # MFMA; its algorithmic bytes (per (t,d) search + rep/id-range fetch + P*S ids) are reported for scale.

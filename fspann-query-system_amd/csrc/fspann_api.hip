@@ -274,7 +274,7 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
         const char* ce = getenv("FSPANN_ROUTE_LAZY_CAP");   // tests: distinct ids one query may hold before it is handed back
         const int cap_env = ce ? atoi(ce) : 0;
         const size_t lds = static_cast<size_t>(kLzHtSize) * 8 + TP * 16 + 4096 + 4096 + (TP + 2) * 8 + (TP + 1) * 4 + 8 +
-                           static_cast<size_t>(c->TD) * 8 + ((TP * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kLzEntries) * 2 + 4096 + 16;
+                           static_cast<size_t>(c->TD) * 8 + ((TP * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kLzEntries) * 2 + 4096 + static_cast<size_t>(c->TD) * 4 + 16;
         if (TP < 32768 && lds <= budget) {
             pl.lazy = 1;
             pl.lazy_cap = (cap_env > 0) ? std::min(cap_env, kLzEntries) : kLzEntries;
@@ -311,11 +311,21 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     if (vec) {
         auto kern = refine_scan_kernel<TC, TQ, DC, true, GATHER>;
         if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {   // start/stop events attached to this very dispatch
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, c->rt_events[c->rt_used], c->rt_events[c->rt_used + 1], 0,
+                                  q, cand, store_n, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
+            c->rt_used += 2;
+        } else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, store_n, B, d, cand_ids, cand_count, k,
                            nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
     } else {
         auto kern = refine_scan_kernel<TC, TQ, DC, false, GATHER>;
         if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {   // start/stop events attached to this very dispatch
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, c->rt_events[c->rt_used], c->rt_events[c->rt_used + 1], 0,
+                                  q, cand, store_n, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
+            c->rt_used += 2;
+        } else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, store_n, B, d, cand_ids, cand_count, k,
                            nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
     }
@@ -419,6 +429,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
     free_dev(c->d_store);
     free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
+    for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -809,12 +820,23 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     { const char* e = getenv("FSPANN_ROUTE_DBG_SKIP"); p.dbg_skip = e ? atoi(e) : 0; }
     p.decimal_ids = c->decimal_ids ? 1 : 0;
     p.out_cap = cap; p.out_ids = ids_dev; p.out_score = score_dev; p.out_count = count_dev; p.out_kept = kept_dev; p.out_raw = raw_seen_dev;
+    bool fused = false;
     if (pl.lazy) {
         if ((rc = ensure(c, c->ws_ovf, static_cast<size_t>(nq) * 4 + 256))) return rc;
+        if (c->ovf_ptr_seen != c->ws_ovf.p) {    // fresh buffer: both overflow counters start at zero
+            FSP_HIP(hipMemsetAsync(c->ws_ovf.p, 0, 256, c->stream));
+            c->ovf_ptr_seen = c->ws_ovf.p;
+        }
+        c->ovf_flip ^= 1;
         p.inv = c->d_inv; p.ids_bk = c->d_ids_bk; p.n_ids = c->n_ids; p.lazy_cap = pl.lazy_cap; p.lz_ht_size = pl.lz_ht_size;
         p.lz_ht_shift = 32 - __builtin_ctz(pl.lz_ht_size);
-        p.ovf_count = static_cast<int32_t*>(c->ws_ovf.p);
-        p.ovf_list = p.ovf_count + 64;
+        p.ovf_count = static_cast<int32_t*>(c->ws_ovf.p) + 16 * c->ovf_flip;          // this call's counter ...
+        p.ovf_next = static_cast<int32_t*>(c->ws_ovf.p) + 16 * (c->ovf_flip ^ 1);      // ... the next call's is zeroed meanwhile
+        p.ovf_list = static_cast<int32_t*>(c->ws_ovf.p) + 64;
+        // the probe runs inside the bounded select when its scratch fits the arrays it borrows there
+        const char* fe = getenv("FSPANN_ROUTE_FUSED_PROBE");
+        fused = !(fe && fe[0] == '0') && (kLzThreads / 16) * (2 * pl.P - 1) * 12 <= 4096 && c->TD <= 512;
+        p.probe_G = fused ? 16 : 0;
     }
     // kernel 1: search + probe order, one lane group per (query, table)
     const size_t TPn = static_cast<size_t>(c->TD) * pl.P;
@@ -822,7 +844,7 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     if ((rc = ensure(c, c->ws_probe, probe_bytes + np_bytes + 256))) return rc;
     int4* probe_dev = static_cast<int4*>(c->ws_probe.p);
     int32_t* nprobe_dev = reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_probe.p) + ((probe_bytes + 255) & ~size_t(255)));
-    {
+    if (!fused) {
         int G = 64;
         while (G > 2 && G / 2 >= 2 * pl.P - 1 && G / 2 >= 16) G >>= 1;  // >= 16 lanes per table: 3-4 search rounds
         const int gpb = kProbeThreads / G;
@@ -1068,12 +1090,46 @@ int fspann_last_route_info(fspann_ctx* c, int* lazy, int* overflowed) {
         if (c->last_route_lazy && c->ws_ovf.p) {
             FSP_HIP(hipStreamSynchronize(c->stream));
             int32_t v = 0;
-            FSP_HIP(hipMemcpy(&v, c->ws_ovf.p, 4, hipMemcpyDeviceToHost));
+            FSP_HIP(hipMemcpy(&v, static_cast<int32_t*>(c->ws_ovf.p) + 16 * c->ovf_flip, 4, hipMemcpyDeviceToHost));
             *overflowed = v;
         }
     }
     return FSPANN_OK;
 }
+// Kernel-attached timing of the refinement scan: between _begin and _end every refine_scan_kernel dispatch of this
+// context carries its own start/stop HIP events (hipExtLaunchKernel), i.e. the duration of the kernel itself on the
+// context's stream — what a rocprofv3 kernel trace reports — without the gaps a record-before / record-after bracket adds.
+// A dispatch with attached events costs a few microseconds of extra stream time, hence `every`: only every n-th one is timed.
+int fspann_refine_timing_begin(fspann_ctx* c, int max_launches, int every) {
+    CHECK_CTX(c);
+    if (max_launches <= 0 || every <= 0) return fail(FSPANN_E_ARG, "max_launches <= 0 or every <= 0");
+    c->rt_every = every;
+    c->rt_seen = 0;
+    while (c->rt_events.size() < static_cast<size_t>(max_launches) * 2) {
+        hipEvent_t e;
+        FSP_HIP(hipEventCreate(&e));
+        c->rt_events.push_back(e);
+    }
+    c->rt_used = 0;
+    c->rt_on = true;
+    return FSPANN_OK;
+}
+int fspann_refine_timing_end(fspann_ctx* c, int* launches, double* total_ms) {
+    CHECK_CTX(c);
+    c->rt_on = false;
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < c->rt_used; i += 2) {
+        float ms = 0.f;
+        FSP_HIP(hipEventElapsedTime(&ms, c->rt_events[i], c->rt_events[i + 1]));
+        tot += ms;
+    }
+    if (launches) *launches = static_cast<int>(c->rt_used / 2);
+    if (total_ms) *total_ms = tot;
+    c->rt_used = 0;
+    return FSPANN_OK;
+}
+
 // Encode path selection: 0 = auto (MFMA pre-filter for nq >= 4096, exact fp64 otherwise), 1 = exact fp64 VALU only,
 // 2 = always MFMA fp32 GEMM + exact re-check.  All modes produce bit-identical hashes and codes.
 int fspann_set_encode_mode(fspann_ctx* c, int mode) {

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -107,6 +108,13 @@ struct fspann_ctx {
     int meta_epoch = 0, bk_epoch = -1;  // d_ids_bk / d_inv are valid for the id metadata of bk_epoch
     int route_mode = 0;              // 0 auto, 1 always route_select_kernel, 2 bounded select whenever its preconditions hold
     fspann::DevBuf ws_ovf;
+    // kernel-attached HIP events of the refinement scan (fspann_refine_timing_begin / _end)
+    std::vector<hipEvent_t> rt_events;   // pairs: start, stop
+    size_t rt_used = 0;
+    int rt_every = 1, rt_seen = 0;       // events go on every rt_every-th dispatch
+    bool rt_on = false;
+    int ovf_flip = 0;                // which of the two overflow counters the last bounded select used
+    void* ovf_ptr_seen = nullptr;    // ws_ovf.p whose counters have been zeroed
     int last_route_lazy = 0;         // 1 if the last fspann_route[_dev] ran the bounded select
     int64_t total_parts = 0, total_ids = 0;
 

@@ -85,7 +85,6 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     extern __shared__ __align__(16) unsigned char smem[];
     TC* tile = reinterpret_cast<TC*>(smem);                                              // [kRefRows][PITCH]
     __shared__ uint64_t s_wcut[kRefRows / 64];
-    __shared__ int s_qbad;
     __shared__ int s_wbase[kRefRows / 64], s_wsurvn[kRefRows / 64];
     const TQ* __restrict__ qrow = q + static_cast<int64_t>(blockIdx.x / nchunks) * d;
 
@@ -93,32 +92,37 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     const int lane = tid & 63, wave = tid >> 6;
     const int64_t qi = blockIdx.x / nchunks;
     const int chunk = blockIdx.x - static_cast<int>(qi) * nchunks;
-    const int cnt = static_cast<int>(min(static_cast<int64_t>(cand_count[qi]), B));
     const int r0 = chunk * kRefRows;
-    const int nrows = max(0, min(kRefRows, cnt - r0));
     const TC* base = GATHER ? cand : cand + (qi * B + r0) * static_cast<int64_t>(d);
-
-    // candidate id of this lane's row: fetched now so the epilogue has no dependent global load
-    const int32_t my_id = (tid < nrows) ? cand_ids[qi * B + r0 + tid] : -1;
-    if (tid == 0) s_qbad = 0;
-    __syncthreads();
-    for (int i = tid; i < d; i += kRefRows)
-        if (!__builtin_isfinite(qrow[i])) s_qbad = 1;   // QSI.java:137-140: invalid query -> empty result
-
+    // The candidate ids do not depend on cand_count: they are requested first (all slots of this chunk that exist in
+    // the [nq][B] id array), so the count, the ids and the query check are ONE global round trip before the rows.
+    const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
+    const int32_t my_id_raw = (tid < rows_here) ? cand_ids[qi * B + r0 + tid] : -1;
     // register double buffering: tile t+1 is in flight (global -> VGPR) while tile t is consumed from LDS
     V reg[VPR];
     // source row of each of this lane's 16-byte slots: the block-local row (dense) or the store row (gather), -1 = none
     int32_t srow[VPR];
+    if constexpr (VEC && GATHER) {
+#pragma unroll
+        for (int i = 0; i < VPR; i++) {
+            const int row = wave * 64 + (lane + i * 64) / VPR;
+            srow[i] = (row < rows_here) ? cand_ids[qi * B + r0 + row] : -1;
+        }
+    }
+    // QSI.java:137-140: a non-finite query gives an empty result.  Every wave looks at the whole query itself.
+    bool qnf = false;
+    for (int i = lane; i < d; i += 64) qnf = qnf || !__builtin_isfinite(qrow[i]);
+    const bool qbad = __any(qnf);
+    const int cnt = static_cast<int>(min(static_cast<int64_t>(cand_count[qi]), B));
+    const int nrows = max(0, min(kRefRows, cnt - r0));
+    // candidate id of this lane's row (the epilogue has no dependent global load)
+    const int32_t my_id = (tid < nrows) ? my_id_raw : -1;
     if constexpr (VEC) {
 #pragma unroll
         for (int i = 0; i < VPR; i++) {
             const int row = wave * 64 + (lane + i * 64) / VPR;
-            if constexpr (GATHER) {
-                const int32_t id = (row < nrows) ? cand_ids[qi * B + r0 + row] : -1;
-                srow[i] = (id >= 0 && id < store_n) ? id : -1;
-            } else {
-                srow[i] = (row < nrows) ? row : -1;
-            }
+            if constexpr (GATHER) srow[i] = (row < nrows && srow[i] >= 0 && srow[i] < store_n) ? srow[i] : -1;
+            else srow[i] = (row < nrows) ? row : -1;
         }
     }
 #define FSP_ISSUE(C0)                                                                                              \
@@ -193,7 +197,6 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
     }
 #undef FSP_ISSUE
 #undef FSP_WAVE_SYNC
-    const bool qbad = (s_qbad != 0);
     const bool valid = (tid < nrows) && ok && !qbad;
     uint64_t key = kInvalidKey;
     if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371

@@ -72,6 +72,8 @@ struct RouteParams {
     int64_t n_ids;
     int lazy_cap;                  // tuples one query may insert before it is handed to route_select_kernel
     int lz_ht_size, lz_ht_shift;
+    int32_t* ovf_next;             // the OTHER overflow counter: zeroed by the lazy kernel for the next call (ping-pong)
+    int probe_G;                   // fused probe: lanes per table (0: the probe list comes from route_probe_kernel)
     int32_t* ovf_count;            // overflow list written by the lazy kernel ...
     int32_t* ovf_list;
     const int32_t* qcount;         // ... and consumed by route_select_kernel (qlist mode: only these queries)
@@ -178,28 +180,17 @@ __device__ __forceinline__ int wave_find_cut(const int32_t* bins, int nb, int ne
 // Kernel 1: search + probe order.  One lane group (G lanes) per (query, table).
 // probe_out[(q*TD + td)*P + step] = {partition, Hamming, id_off b0, size}; nprobe_out[q*TD + td].
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams prm, int4* __restrict__ probe_out,
-                                                                   int32_t* __restrict__ nprobe_out, int G) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int TD = prm.TD, W = prm.W, P = prm.P;
+// Probe list of ONE (query, table) by one group of G lanes (G | 64, group-aligned inside a wave): the partitions
+// PIS.lookupCandidatesWithScores visits for this table, in the reference's order.  `act` = the group has a table to work on
+// (every lane of the wave must call: ballots inside).  w3 = LDS scratch of the group, (2P-1)*3 ints.  The list goes to
+// po[0..np) (LDS or global); returns np.
+template <typename OutPtr>
+__device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool act, const uint64_t* qc, const RouteTable tb, int G, int gl,
+                                                 int grp_in_wave, int32_t* w3, OutPtr po) {
+    const int W = prm.W, P = prm.P;
     const int nd = 2 * P - 1;
-    const int gpb = kProbeThreads / G;                 // groups per block
-    const int grp_in_wave = lane / G, gl = lane - grp_in_wave * G;
-    const int grp_in_block = tid / G;
+    act = act && tb.nparts > 0;
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp_in_wave * G));
-    int32_t* w3 = reinterpret_cast<int32_t*>(smem) + static_cast<size_t>(grp_in_block) * nd * 3;  // [nd][3]
-
-    if (prm.ovf_count && blockIdx.x == 0 && tid == 0) *prm.ovf_count = 0;   // stream-ordered before the select kernels
-    const int64_t item = static_cast<int64_t>(blockIdx.x) * gpb + grp_in_block;  // (q, td) flattened
-    const int64_t nitems = prm.nq * TD;
-    const bool in_range = item < nitems;
-    const int64_t qi = in_range ? item / TD : 0;
-    const int td = in_range ? static_cast<int>(item - qi * TD) : 0;
-    const RouteTable tb = prm.tables[td];
-    const bool act = in_range && tb.nparts > 0;
-    const uint64_t* qc = prm.codes + (qi * TD + td) * W;
     // GreedyPartitioner.computeKey: code bit i -> key bit 62-i (i < 63)
     const int64_t qKey = act ? static_cast<int64_t>(__brevll(qc[0]) >> 1) : 0;
     const int64_t* k2 = prm.keys2 + tb.part_base * 2;
@@ -270,12 +261,12 @@ __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams 
             w3[l * 3 + 0] = dd; w3[l * 3 + 1] = b0; w3[l * 3 + 2] = sz;
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    int np = 0;
     if (act) {
         // java.util.PriorityQueue with <= 2 live entries: offer() makes the newcomer the root only
         // if STRICTLY smaller (siftUp); poll() promotes the survivor (siftDown on one element).
-        int4* po = probe_out + item * P;
-        int np = 0;
         int h_idx0 = center, h_d0 = w3[(P - 1) * 3];
         int h_idx1 = 0, h_d1 = 0, hn = 1;
         int vlo = center, vhi = center;
@@ -309,10 +300,31 @@ __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams 
                 hn++;
             }
         }
-        if (gl == 0) nprobe_out[item] = np;
-    } else if (in_range && gl == 0) {
-        nprobe_out[item] = 0;
     }
+    return np;
+}
+
+__global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams prm, int4* __restrict__ probe_out,
+                                                                   int32_t* __restrict__ nprobe_out, int G) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int TD = prm.TD, W = prm.W, P = prm.P;
+    const int nd = 2 * P - 1;
+    const int gpb = kProbeThreads / G;                 // groups per block
+    const int grp_in_wave = lane / G, gl = lane - grp_in_wave * G;
+    const int grp_in_block = tid / G;
+    int32_t* w3 = reinterpret_cast<int32_t*>(smem) + static_cast<size_t>(grp_in_block) * nd * 3;  // [nd][3]
+
+    const int64_t item = static_cast<int64_t>(blockIdx.x) * gpb + grp_in_block;  // (q, td) flattened
+    const int64_t nitems = prm.nq * TD;
+    const bool in_range = item < nitems;
+    const int64_t qi = in_range ? item / TD : 0;
+    const int td = in_range ? static_cast<int>(item - qi * TD) : 0;
+    const RouteTable tb = prm.tables[td];
+    const uint64_t* qc = prm.codes + (qi * TD + td) * W;
+    const int np = route_probe_table(prm, in_range, qc, tb, G, gl, grp_in_wave, w3, probe_out + item * P);
+    if (in_range && gl == 0) nprobe_out[item] = np;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -76,8 +76,8 @@ __device__ __forceinline__ int wave_cut1024(const int32_t* bins, int need, int l
 }
 
 template <int kThreads>
-__global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RouteParams prm, const int4* __restrict__ probe_in,
-                                                                        const int32_t* __restrict__ nprobe_in) {
+__global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RouteParams prm, int4* __restrict__ probe_in,
+                                                                        int32_t* __restrict__ nprobe_in) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
     constexpr int nthreads = kThreads;
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
     uint16_t* ord = reinterpret_cast<uint16_t*>(smem + o);       o += (static_cast<size_t>(TP) * 2 + 3) & ~size_t(3);
     uint16_t* ulist = reinterpret_cast<uint16_t*>(smem + o);     o += static_cast<size_t>(kLzEntries) * 2;   // hash slots of the entries
     uint16_t* rk = reinterpret_cast<uint16_t*>(smem + o);        o += 1024 * 2;   // entries per (score, bucket) rank: > 1 = collision
-    uint16_t* lrank = reinterpret_cast<uint16_t*>(smem + o);     // [1024] (score, bucket) rank of each entry
+    uint16_t* lrank = reinterpret_cast<uint16_t*>(smem + o);     o += 1024 * 2;   // (score, bucket) rank of each entry
+    int32_t* nprobe_l = reinterpret_cast<int32_t*>(smem + o);    // [TD] fused probe: partitions probed per table
     // collision records alias the histogram (free once the levels are in): element, prefix rank, id, sequence
     int32_t* c_elem = bins;
     int32_t* c_lt = bins + kLzCollMax;
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
 
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
     for (int i = tid; i < kLzHtSize; i += nthreads) ht[i] = kLzEmpty;
+    if (blockIdx.x == 0 && tid == 0) *prm.ovf_next = 0;   // the other counter, for the next call (stream-ordered after this one)
 
     // is `id` already an entry?  (an entry of an earlier level: its score is lower, this occurrence changes nothing)
     auto present = [&](int32_t id) -> bool {
@@ -197,12 +199,35 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
     for (int64_t qi = blockIdx.x; qi < prm.nq; qi += gridDim.x) {
         LZ_STAMP(0);
         // ---- probe list of this query; unused steps get an impossible partition and sort last ------------------
-        for (int i = tid; i < TP; i += nthreads) {
-            const int td = i / P, step = i - td * P;
-            int4 e = make_int4(-1, 0x7FFF, 0, 0);
-            if (step < nprobe_in[qi * TD + td]) e = probe_in[qi * TP + i];
-            plist[i] = e;
-            pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
+        if (prm.probe_G > 0) {
+            // fused probe (route_probe_table): one group of G lanes per table, all tables of the query side by side
+            const int G = prm.probe_G, ngroups = nthreads / G;
+            const int grp_in_wave = lane / G, gl = lane - grp_in_wave * G, grp = tid / G;
+            int32_t* w3 = reinterpret_cast<int32_t*>(pre) + grp * (2 * P - 1) * 3;     // `pre` is free until the rank pass
+            for (int t0 = 0; t0 < TD; t0 += ngroups) {                                 // block-uniform trip count
+                const int td = t0 + grp;
+                const bool act = td < TD;
+                const int tdc = act ? td : 0;
+                const int np = route_probe_table(prm, act, prm.codes + (qi * TD + tdc) * prm.W, prm.tables[tdc], G, gl, grp_in_wave,
+                                                 w3, plist + tdc * P);
+                if (act && gl == 0) nprobe_l[td] = np;
+            }
+            __syncthreads();
+            for (int i = tid; i < TP; i += nthreads) {
+                const int td = i / P, step = i - td * P;
+                int4 e = make_int4(-1, 0x7FFF, 0, 0);
+                if (step < nprobe_l[td]) e = plist[i];
+                plist[i] = e;
+                pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
+            }
+        } else {
+            for (int i = tid; i < TP; i += nthreads) {
+                const int td = i / P, step = i - td * P;
+                int4 e = make_int4(-1, 0x7FFF, 0, 0);
+                if (step < nprobe_in[qi * TD + td]) e = probe_in[qi * TP + i];
+                plist[i] = e;
+                pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
+            }
         }
         if (tid == 0) { s_u = 0; s_R = TP; s_ncoll = 0; s_bad = 0; s_short = 0; pkv[TP] = make_uint2(0xFFFFFFFFu, 0u); }
         __syncthreads();
@@ -482,7 +507,13 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             }
             if (!overflow && tid == 0) prm.out_count[qi] = nout;
         }
-        if (overflow && tid == 0) prm.ovf_list[atomicAdd(prm.ovf_count, 1)] = static_cast<int32_t>(qi);
+        if (overflow) {
+            if (prm.probe_G > 0) {   // the full select reads the probe lists from global memory: hand this query's over
+                for (int i = tid; i < TP; i += nthreads) probe_in[qi * TP + i] = plist[i];
+                for (int i = tid; i < TD; i += nthreads) nprobe_in[qi * TD + i] = nprobe_l[i];
+            }
+            if (tid == 0) prm.ovf_list[atomicAdd(prm.ovf_count, 1)] = static_cast<int32_t>(qi);
+        }
         __syncthreads();
         LZ_STAMP(6);
         // ---- clear exactly the slots this query used ---------------------------------------------------------------

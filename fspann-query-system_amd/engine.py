@@ -269,6 +269,16 @@ class FspannContext:
     def store_gather_dev(self, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr):
         N.check(self.L.fspann_store_gather_dev(self._h, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr))
 
+    def refine_timing_begin(self, max_launches, every=1):
+        N.check(self.L.fspann_refine_timing_begin(self._h, int(max_launches), int(every)))
+
+    def refine_timing_end(self):
+        """(dispatches, total ms) of the refinement-scan kernels launched since refine_timing_begin (kernel-attached HIP events)."""
+        import ctypes as C
+        n, ms = C.c_int(0), C.c_double(0.0)
+        N.check(self.L.fspann_refine_timing_end(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def refine_store_dev(self, nq, q_ptr, q_dtype, B, cand_ids_ptr, cand_count_ptr, k, out_ids_ptr, out_dist_ptr,
                          out_count_ptr, scored_ptr=0):
         N.check(self.L.fspann_refine_store_dev(self._h, nq, q_ptr, q_dtype, B, cand_ids_ptr, cand_count_ptr, k,

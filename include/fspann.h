@@ -178,6 +178,13 @@ int fspann_refine_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtyp
                       int cand_dtype, int64_t B, const int32_t* cand_ids_dev, const int32_t* cand_count_dev, int k,
                       int32_t* out_ids_dev, double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev);
 
+/* Measurement aid: between _begin and _end every refinement-scan dispatch of this context carries its own
+ * start/stop HIP events (kernel-attached, on the context's stream); _end synchronises and returns the number of
+ * timed dispatches and the sum of their durations.  Only every `every`-th dispatch is timed (an attached pair
+ * costs a few microseconds of stream time); max_launches bounds the events kept.                          */
+int fspann_refine_timing_begin(fspann_ctx* ctx, int max_launches, int every);
+int fspann_refine_timing_end(fspann_ctx* ctx, int* launches, double* total_ms);
+
 /* ---- plaintext store (TEST / BENCH harness only) ----------------------------------------
  * Stand-in for the host's loadPointIfActive + decryptFromPoint (PIS:717-724;
  * crypto/AesGcmCryptoService.java:126-166), which stay on the host in production: keeps
