@@ -211,6 +211,30 @@ def test_bounded_select_degenerate_hash_hands_back(pkg, oracle):
     assert np.array_equal(lazy["ids"], full["ids"]) and np.array_equal(lazy["score"], full["score"])
 
 
+@pytest.mark.parametrize("block_size", [16, 100, 128])
+def test_bounded_select_other_block_sizes(pkg, oracle, block_size):
+    """The reference's block size is the constant 64 (PIS:92); the library takes others.  Partitions that are not one
+    wave wide go through the whole-partition path of the bounded select: compared with the full select."""
+    sc = make_scene(oracle, n=20000, d=16, T=6, D=1, m=12, lam=2, B=200, seed=31 + block_size)
+    p = sc["params"]
+    codes = sc["oracle"].encode(sc["rng"].standard_normal((20, 16)))
+    cfg = pkg.PaperRuntimeConfig(tables=p["T"], divisions=p["D"], m=p["m"], lambda_=p["lam"], dim=p["d"], refinement_limit=p["B"],
+                                 block_size=block_size)
+    with pkg.FspannContext(cfg, 0) as ctx:
+        ctx.set_gfunctions(sc["alpha"], sc["r"], sc["omega"])
+        ctx.set_id_meta(p["n"])
+        ctx.build_index(sc["X"])
+        for lim in (200, 33):
+            full = ctx.route(codes, limit=lim)
+            ctx.set_route_mode(2)
+            lazy = ctx.route(codes, limit=lim, counters=False)
+            info = ctx.last_route_info()
+            ctx.set_route_mode(0)
+            assert info["lazy"] and info["overflowed"] == 0
+            assert np.array_equal(lazy["count"], full["count"])
+            assert np.array_equal(lazy["ids"], full["ids"]) and np.array_equal(lazy["score"], full["score"])
+
+
 def test_bounded_select_hands_back_large_queries(pkg, oracle, monkeypatch):
     """Queries whose entries exceed what the bounded select may hold are redone by the full select."""
     sc = make_scene(oracle, n=40000, d=16, T=10, D=1, m=12, lam=2, B=256, seed=23)
