@@ -166,6 +166,22 @@ def main():
         qp = q_all[(step_no[0] // active[0]) % NB].data_ptr() if batch is None else q_all[batch].data_ptr()
         step_no[0] += 1
         cx, stream, b = ctxs[si], streams[si], bufs[si]
+        if events is None and not dense and not args.route_counters:
+            # the whole step in ONE library call (encode -> route(limit = B) -> refine from the store, stream order)
+            par = b["nsteps"] & 1
+            b["nsteps"] += 1
+            if use_dist and b["nsteps"] > 2:
+                stream.wait_event(b["ev_gath"][par])      # the all-gather that last read this result buffer has finished
+            cx.search_store_dev(Q, qp, F32, -1, B, k, b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(),
+                                b["out_cnt"].data_ptr(), b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(),
+                                b["bad"].data_ptr())
+            if use_dist:
+                b["ev_done"][par].record(stream)
+                side.wait_event(b["ev_done"][par])
+                with torch.cuda.stream(side):
+                    fdist.allgather_topk(b["topk"][par], b["gathered"][par])
+                    b["ev_gath"][par].record(side)
+            return
         if events is not None and not ref_only:
             events[0].record(stream)
         cx.encode_dev(Q, qp, F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())

@@ -119,6 +119,7 @@ _SIGS = {
     "fspann_refine_store_dev": (_i, [_vp, _i64, _vp, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "fspann_refine_timing_begin": (_i, [_vp, _i, _i]),
     "fspann_refine_timing_end": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double)]),
+    "fspann_search_store_dev": (_i, [_vp, _i64, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fspann_store_set": (_i, [_vp, _i64, _vp, _i]),
     "fspann_store_gather_dev": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "fspann_store_dev_ptr": (_vp, [_vp, C.POINTER(_i)]),

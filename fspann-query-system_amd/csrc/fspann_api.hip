@@ -428,7 +428,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
     free_dev(c->d_store);
-    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
+    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1042,6 +1042,34 @@ int fspann_refine_store(fspann_ctx* c, int64_t nq, const void* q, int q_dtype, i
     if (scored) FSP_HIP(hipMemcpyAsync(scored, cnts + 2 * nq, nb, hipMemcpyDeviceToHost, c->stream));
     FSP_HIP(hipStreamSynchronize(c->stream));
     return FSPANN_OK;
+}
+
+// QueryServiceImpl.search for a batch, all three stages in stream order with one call: TokenGen codes (encode),
+// Route with limit = B (stage A.5; counters not produced, so the bounded select may run), Refine from the resident store.
+// The adaptive retry (QSI:327-337) stays with the caller: out_count / scored tell it when to call again with
+// probe_override = 10.  sel_ids_dev / sel_count_dev (optional) receive F_q.
+int fspann_search_store_dev(fspann_ctx* c, int64_t nq, const void* q_dev, int q_dtype, int probe_override, int64_t B, int k,
+                            int32_t* out_ids_dev, double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev,
+                            int32_t* sel_ids_dev, int32_t* sel_count_dev, int32_t* bad_dev) {
+    CHECK_CTX(c);
+    if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
+    if (!c->d_store) return fail(FSPANN_E_STATE, "plaintext store not set");
+    if (nq < 0 || B <= 0 || B > INT32_MAX) return fail(FSPANN_E_ARG, "nq < 0 or B out of range");
+    if (k <= 0) return fail(FSPANN_E_ARG, "topK must be > 0");
+    if (nq == 0) return FSPANN_OK;
+    const size_t cb = (static_cast<size_t>(nq) * c->TD * c->W * 8 + 255) & ~size_t(255);
+    const size_t ib = (static_cast<size_t>(nq) * B * 4 + 255) & ~size_t(255);
+    const size_t nb = (static_cast<size_t>(nq) * 4 + 255) & ~size_t(255);
+    int rc;
+    if ((rc = ensure(c, c->ws_search, cb + ib + 2 * nb))) return rc;
+    char* w = static_cast<char*>(c->ws_search.p);
+    uint64_t* codes = reinterpret_cast<uint64_t*>(w);
+    int32_t* sel = sel_ids_dev ? sel_ids_dev : reinterpret_cast<int32_t*>(w + cb);
+    int32_t* cnt = sel_count_dev ? sel_count_dev : reinterpret_cast<int32_t*>(w + cb + ib);
+    int32_t* bad = bad_dev ? bad_dev : reinterpret_cast<int32_t*>(w + cb + ib + nb);
+    if ((rc = fspann_encode_dev(c, nq, q_dev, q_dtype, codes, nullptr, bad))) return rc;
+    if ((rc = fspann_route_dev(c, nq, codes, probe_override, static_cast<int32_t>(B), B, sel, nullptr, cnt, nullptr, nullptr))) return rc;
+    return fspann_refine_store_dev(c, nq, q_dev, q_dtype, B, sel, cnt, k, out_ids_dev, out_dist_dev, out_count_dev, scored_dev);
 }
 
 const void* fspann_store_dev_ptr(fspann_ctx* c, int* dtype) {

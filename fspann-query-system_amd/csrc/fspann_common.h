@@ -113,6 +113,7 @@ struct fspann_ctx {
     size_t rt_used = 0;
     int rt_every = 1, rt_seen = 0;       // events go on every rt_every-th dispatch
     bool rt_on = false;
+    fspann::DevBuf ws_search;        // codes / F_q ids / counts of fspann_search_store_dev
     int ovf_flip = 0;                // which of the two overflow counters the last bounded select used
     void* ovf_ptr_seen = nullptr;    // ws_ovf.p whose counters have been zeroed
     int last_route_lazy = 0;         // 1 if the last fspann_route[_dev] ran the bounded select

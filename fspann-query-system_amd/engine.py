@@ -269,6 +269,13 @@ class FspannContext:
     def store_gather_dev(self, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr):
         N.check(self.L.fspann_store_gather_dev(self._h, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr))
 
+    def search_store_dev(self, nq, q_ptr, q_dtype, probe_override, B, k, out_ids_ptr, out_dist_ptr, out_count_ptr, scored_ptr=0,
+                         sel_ids_ptr=0, sel_count_ptr=0, bad_ptr=0):
+        """encode -> route(limit = B) -> refine from the resident store, one call (device pointers, stream order)."""
+        N.check(self.L.fspann_search_store_dev(self._h, nq, q_ptr, q_dtype, probe_override, B, k, out_ids_ptr, out_dist_ptr,
+                                               out_count_ptr, scored_ptr or None, sel_ids_ptr or None, sel_count_ptr or None,
+                                               bad_ptr or None))
+
     def refine_timing_begin(self, max_launches, every=1):
         N.check(self.L.fspann_refine_timing_begin(self._h, int(max_launches), int(every)))
 

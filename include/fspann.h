@@ -202,6 +202,13 @@ int fspann_refine_store(fspann_ctx* ctx, int64_t nq, const void* q, int q_dtype,
 int fspann_refine_store_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtype, int64_t B,
                             const int32_t* cand_ids_dev, const int32_t* cand_count_dev, int k, int32_t* out_ids_dev,
                             double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev);
+/* QueryServiceImpl.search (QSI:101-352) for a batch whose candidate rows are resident in the store: encode ->
+ * route(limit = B, counters not produced) -> refine_store, enqueued in stream order by one call.  The adaptive
+ * retry (QSI:327-337) stays with the caller (out_count / scored say when).  Optional outputs may be NULL:
+ * scored, sel_ids [nq][B] + sel_count [nq] (= F_q), bad [nq] (1 = query held NaN/Inf, QueryTokenFactory rejects). */
+int fspann_search_store_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtype, int probe_override, int64_t B,
+                            int k, int32_t* out_ids_dev, double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev,
+                            int32_t* sel_ids_dev, int32_t* sel_count_dev, int32_t* bad_dev);
 const void* fspann_store_dev_ptr(fspann_ctx* ctx, int* dtype);
 
 /* ---- device memory helpers (so non-torch callers can own HBM buffers) ------------------- */
