@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--query-batches", type=int, default=8,
                     help="distinct query batches cycled through by the steps (a repeated batch would re-read the same "
                          "candidate rows out of the 256 MiB Infinity Cache instead of HBM)")
+    ap.add_argument("--merge", default="inline", choices=["inline", "overlap"],
+                    help="N > 1: the RCCL all-gather of the per-rank top-k follows Refine on the same stream (inline), or runs on "
+                         "a side stream overlapping the next step (overlap; costs two cross-stream events per step)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream pass reported under 'pipelined'")
     ap.add_argument("--route-counters", action="store_true",
                     help="also produce lastCandKept / rawSeen per query (forces the full select)")
@@ -133,6 +136,21 @@ def main():
     q_dev = q_all[0]
     from fspann_amd import dist as fdist
 
+    class _TorchEv:          # same interface over a default torch event (system-scope fence on record)
+        def __init__(self):
+            self.e = torch.cuda.Event()
+
+        def record(self, st):
+            self.e.record(st)
+
+        def wait(self, st):
+            st.wait_event(self.e)
+
+    def mkev():
+        if use_dist:
+            return fdist.DeviceEvent()        # device-scope release: no L2 writeback/invalidate per hand-off
+        return _TorchEv()
+
     def mkbufs():
         return dict(codes=torch.zeros((Q, TD, W), dtype=torch.int64, device=dev), bad=torch.zeros(Q, dtype=torch.int32, device=dev),
                     sel_ids=torch.full((Q, B), -1, dtype=torch.int32, device=dev), sel_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
@@ -143,17 +161,34 @@ def main():
                     topk=[fdist.TopkBuffer(Q, k, dev) for _ in range(2)],
                     out_cnt=torch.zeros(Q, dtype=torch.int32, device=dev), scored=torch.zeros(Q, dtype=torch.int32, device=dev),
                     gathered=[fdist.GatheredTopk(world, Q, k, dev) for _ in range(2)] if use_dist else None,
-                    ev_done=[torch.cuda.Event() for _ in range(2)], ev_gath=[torch.cuda.Event() for _ in range(2)], nsteps=0)
+                    ev_done=[mkev() for _ in range(2)], ev_gath=[mkev() for _ in range(2)], nsteps=0)
 
     bufs = [mkbufs() for _ in ctxs]
     out_ids, out_dist = bufs[0]["topk"][0].ids, bufs[0]["topk"][0].dist
     gathered = bufs[0]["gathered"][0] if use_dist else None
     side = torch.cuda.Stream(device=dev) if use_dist else None
+    # the collective is issued straight through librccl when that works (host cost per call: us instead of ~80 us)
+    rccl = fdist.DirectRccl(world, rank, dev) if use_dist else None
+    if use_dist:
+        flag = torch.tensor([1 if rccl.ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks or none
+        if int(flag.item()) == 0:
+            rccl.ok = False
+    def merge(local, out, st):
+        """the ONE collective of the path, issued on stream `st`"""
+        if rccl.ok:
+            rccl.allgather_topk(local, out, st)
+        else:
+            with torch.cuda.stream(st):
+                fdist.allgather_topk(local, out)
+
+    gather_path = "ncclAllGather via librccl (direct)" if (use_dist and rccl.ok) else ("torch.distributed all_gather_into_tensor" if use_dist else None)
     torch.cuda.synchronize()
 
     streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
     F32 = pkg._native.F32
     step_no = [0]
+    inline_merge = (args.merge == "inline")
     active = [max(1, args.streams)]          # contexts the steps alternate between
     dense = (args.candidates == "dense")
 
@@ -170,17 +205,21 @@ def main():
             # the whole step in ONE library call (encode -> route(limit = B) -> refine from the store, stream order)
             par = b["nsteps"] & 1
             b["nsteps"] += 1
-            if use_dist and b["nsteps"] > 2:
-                stream.wait_event(b["ev_gath"][par])      # the all-gather that last read this result buffer has finished
+            if use_dist and b["nsteps"] > 2 and not inline_merge:
+                b["ev_gath"][par].wait(stream)            # the all-gather that last read this result buffer has finished
             cx.search_store_dev(Q, qp, F32, -1, B, k, b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(),
                                 b["out_cnt"].data_ptr(), b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(),
                                 b["bad"].data_ptr())
+            if use_dist and inline_merge:
+                # the collective follows Refine on the SAME stream: no cross-stream events (each costs this stream two
+                # extra barrier packets, ~20 us per step on this runtime — more than the all-gather itself)
+                merge(b["topk"][par], b["gathered"][par], stream)
+                return
             if use_dist:
                 b["ev_done"][par].record(stream)
-                side.wait_event(b["ev_done"][par])
-                with torch.cuda.stream(side):
-                    fdist.allgather_topk(b["topk"][par], b["gathered"][par])
-                    b["ev_gath"][par].record(side)
+                b["ev_done"][par].wait(side)
+                merge(b["topk"][par], b["gathered"][par], side)
+                b["ev_gath"][par].record(side)
             return
         if events is not None and not ref_only:
             events[0].record(stream)
@@ -199,8 +238,8 @@ def main():
             events[3].record(stream)
         par = b["nsteps"] & 1
         b["nsteps"] += 1
-        if use_dist and b["nsteps"] > 2:
-            stream.wait_event(b["ev_gath"][par])      # the all-gather that last read this result buffer has finished
+        if use_dist and b["nsteps"] > 2 and not inline_merge:
+            b["ev_gath"][par].wait(stream)            # the all-gather that last read this result buffer has finished
         if dense:
             cx.refine_dev(Q, qp, F32, b["cand"].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
                           b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
@@ -210,14 +249,15 @@ def main():
                                 b["scored"].data_ptr())
         if events is not None:
             events[4].record(stream)
-        if use_dist:
-            # the one collective of the path: all-gather of [Q x k] (id, dist) per rank over RCCL/xGMI, on a side
-            # stream so that it overlaps the next step's kernels
+        if use_dist and inline_merge:
+            merge(b["topk"][par], b["gathered"][par], stream)
+        elif use_dist:
+            # --merge overlap: the all-gather of [Q x k] (id, dist) per rank on a side stream, so that it overlaps the
+            # next step's kernels (two events per step; see --merge)
             b["ev_done"][par].record(stream)
-            side.wait_event(b["ev_done"][par])
-            with torch.cuda.stream(side):
-                fdist.allgather_topk(b["topk"][par], b["gathered"][par])
-                b["ev_gath"][par].record(side)
+            b["ev_done"][par].wait(side)
+            merge(b["topk"][par], b["gathered"][par], side)
+            b["ev_gath"][par].record(side)
 
     def barrier():
         for c_ in ctxs:
@@ -396,7 +436,7 @@ def main():
             "data": "synthetic N(0,1) fp32 vectors (SIFT-1M shape), exact-kNN ground truth of the synthetic set",
             "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
                        "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "distinct_query_batches": NB, "route_counters": bool(args.route_counters),
-                       "parallelism": f"query-sharded x{world}, index replicated", "streams_per_gpu": active[0],
+                       "parallelism": f"query-sharded x{world}, index replicated", "merge": (gather_path + (", same stream" if inline_merge else ", side stream")) if use_dist else None, "streams_per_gpu": active[0],
                        "candidates": "rows read from the HBM-resident plaintext store by id inside the refine scan" if not dense
                        else "rows packed into [Q][B][d] by a gather kernel (host decrypt stand-in), then scanned"},
             "recall_at_10": recall,
@@ -418,6 +458,7 @@ def main():
     for c_ in ctxs:
         c_.close()
     if use_dist:
+        rccl.close()
         dist.destroy_process_group()
 
 
