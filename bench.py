@@ -189,6 +189,10 @@ def main():
     F32 = pkg._native.F32
     step_no = [0]
     inline_merge = (args.merge == "inline")
+    # QSI's adaptive retry (QSI:327-337,444-447): one more pass with 10 probes when returned < K or decrypted < 10*K.
+    # With B < 10*K the second condition always holds (decrypted <= B), so every query takes both passes and the second
+    # one is the answer; with B >= 10*K (and >= K finite candidates, true for the synthetic data) it never triggers.
+    probe_passes = [-1, 10] if B < 10 * k else [-1]
     active = [max(1, args.streams)]          # contexts the steps alternate between
     dense = (args.candidates == "dense")
 
@@ -207,9 +211,10 @@ def main():
             b["nsteps"] += 1
             if use_dist and b["nsteps"] > 2 and not inline_merge:
                 b["ev_gath"][par].wait(stream)            # the all-gather that last read this result buffer has finished
-            cx.search_store_dev(Q, qp, F32, -1, B, k, b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(),
-                                b["out_cnt"].data_ptr(), b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(),
-                                b["bad"].data_ptr())
+            for pov in probe_passes:
+                cx.search_store_dev(Q, qp, F32, pov, B, k, b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(),
+                                    b["out_cnt"].data_ptr(), b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(),
+                                    b["bad"].data_ptr())
             if use_dist and inline_merge:
                 # the collective follows Refine on the SAME stream: no cross-stream events (each costs this stream two
                 # extra barrier packets, ~20 us per step on this runtime — more than the all-gather itself)
@@ -221,6 +226,10 @@ def main():
                 merge(b["topk"][par], b["gathered"][par], side)
                 b["ev_gath"][par].record(side)
             return
+        for pov in probe_passes[:-1]:   # first pass of the adaptive retry (see probe_passes); the stages below are the last pass
+            cx.search_store_dev(Q, qp, F32, pov, B, k, b["topk"][0].ids.data_ptr(), b["topk"][0].dist.data_ptr(),
+                                b["out_cnt"].data_ptr(), b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(),
+                                b["bad"].data_ptr())
         if events is not None and not ref_only:
             events[0].record(stream)
         cx.encode_dev(Q, qp, F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())
@@ -228,7 +237,7 @@ def main():
             events[1].record(stream)
         # lastCandKept / rawSeen are profiler counters of the reference (QSI metrics), not inputs of Refine: they are
         # only computed on request (--route-counters), which forces the full select over every probed partition
-        cx.route_dev(Q, b["codes"].data_ptr(), -1, B, B, b["sel_ids"].data_ptr(), 0, b["sel_cnt"].data_ptr(),
+        cx.route_dev(Q, b["codes"].data_ptr(), probe_passes[-1], B, B, b["sel_ids"].data_ptr(), 0, b["sel_cnt"].data_ptr(),
                      b["kept"].data_ptr() if args.route_counters else 0, b["raw"].data_ptr() if args.route_counters else 0)
         if events is not None and not ref_only:
             events[2].record(stream)
@@ -435,7 +444,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic N(0,1) fp32 vectors (SIFT-1M shape), exact-kNN ground truth of the synthetic set",
             "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
-                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "distinct_query_batches": NB, "route_counters": bool(args.route_counters),
+                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "distinct_query_batches": NB, "route_counters": bool(args.route_counters), "passes_per_step": len(probe_passes),
                        "parallelism": f"query-sharded x{world}, index replicated", "merge": (gather_path + (", same stream" if inline_merge else ", side stream")) if use_dist else None, "streams_per_gpu": active[0],
                        "candidates": "rows read from the HBM-resident plaintext store by id inside the refine scan" if not dense
                        else "rows packed into [Q][B][d] by a gather kernel (host decrypt stand-in), then scanned"},
