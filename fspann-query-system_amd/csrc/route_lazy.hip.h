@@ -483,25 +483,39 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             if (ncoll > kLzCollMax) {
                 overflow = true;
             } else if (ncoll > 0) {
-                // ---- 4. reference insertion sequence of the colliding entries: one (entry, table) pair per thread ----
-                for (int t = tid; t < ncoll * TD; t += nthreads) {
-                    const int c = t / TD, td = t - c * TD;
-                    const int32_t idx = prm.inv[static_cast<int64_t>(td) * prm.n_ids + c_id[c]];
-                    if (idx < 0) continue;
-                    for (int step = 0; step < P; step++) {
-                        const int4 e = plist[td * P + step];
-                        if (e.x >= 0 && idx >= e.z && idx < e.z + e.w) { atomicMin(&c_seq[c], (td * P + step) * S + (idx - e.z)); break; }
+                // ---- 4. reference insertion sequence of the colliding entries: one (entry, table) pair per thread, the
+                // inverse-map loads of up to four pairs in flight together ----
+                const int npair = ncoll * TD;
+                for (int t0 = tid; t0 < npair; t0 += nthreads * 4) {
+                    int32_t idxv[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int t = t0 + v * nthreads;
+                        idxv[v] = (t < npair) ? prm.inv[static_cast<int64_t>(t % TD) * prm.n_ids + c_id[t / TD]] : -1;
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int t = t0 + v * nthreads;
+                        const int32_t idx = idxv[v];
+                        if (idx < 0) continue;
+                        const int c = t / TD, td = t - c * TD;
+                        for (int step = 0; step < P; step++) {
+                            const int4 e = plist[td * P + step];
+                            if (e.x >= 0 && idx >= e.z && idx < e.z + e.w) { atomicMin(&c_seq[c], (td * P + step) * S + (idx - e.z)); break; }
+                        }
                     }
                 }
+                for (int c = tid; c < ncoll; c += nthreads) c_elem[c] = static_cast<int32_t>(pre[c_elem[c]]);   // element -> its key
                 __syncthreads();
                 for (int c = tid; c < ncoll; c += nthreads) {
-                    const uint32_t my = pre[c_elem[c]];
+                    const int32_t my = c_elem[c];
                     const int myseq = c_seq[c];
                     int rank = c_lt[c];
-                    for (int c2 = 0; c2 < ncoll; c2++) rank += (pre[c_elem[c2]] == my) && (c_seq[c2] < myseq);
+#pragma unroll 4
+                    for (int c2 = 0; c2 < ncoll; c2++) rank += (c_elem[c2] == my) && (c_seq[c2] < myseq);
                     if (rank < nout) {
                         prm.out_ids[qi * prm.out_cap + rank] = c_id[c];
-                        if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = static_cast<int32_t>(my >> kBucketBits);
+                        if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = static_cast<int32_t>(static_cast<uint32_t>(my) >> kBucketBits);
                     }
                 }
             }
