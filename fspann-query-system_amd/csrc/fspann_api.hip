@@ -857,17 +857,20 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
 #define FSP_LAUNCH_SEL(LDS, THR)                                                                                         \
     do {                                                                                                                 \
         auto kern = route_select_kernel<LDS, THR>;                                                                       \
-        FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                    static_cast<int>(pl.lds_bytes)));                                                    \
+        const unsigned abit = 1u << ((LDS ? 0 : 2) + (THR == 1024 ? 1 : 0));                                             \
+        if (!(c->attr_mask & abit)) {   /* once per context: the attribute is the ceiling, not the launch size */        \
+            FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        159 * 1024));                                                                    \
+            c->attr_mask |= abit;                                                                                        \
+        }                                                                                                                \
         hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(THR), pl.lds_bytes, c->stream, p, probe_dev, nprobe_dev);           \
     } while (0)
     c->last_route_lazy = pl.lazy;
     if (pl.lazy) {
         auto lk = route_select_lazy_kernel<kLzThreads>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!(c->attr_mask & 16u)) {
             FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-            attr_set = true;
+            c->attr_mask |= 16u;
         }
         hipLaunchKernelGGL(lk, dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p, probe_dev, nprobe_dev);
         FSP_HIP(hipGetLastError());

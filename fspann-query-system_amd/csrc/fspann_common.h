@@ -114,6 +114,7 @@ struct fspann_ctx {
     int rt_every = 1, rt_seen = 0;       // events go on every rt_every-th dispatch
     bool rt_on = false;
     fspann::DevBuf ws_search;        // codes / F_q ids / counts of fspann_search_store_dev
+    unsigned attr_mask = 0;          // kernels whose dynamic-LDS ceiling has been raised on this context's device
     int ovf_flip = 0;                // which of the two overflow counters the last bounded select used
     void* ovf_ptr_seen = nullptr;    // ws_ovf.p whose counters have been zeroed
     int last_route_lazy = 0;         // 1 if the last fspann_route[_dev] ran the bounded select
