@@ -47,12 +47,15 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
     const int p = td0 * m + tid;
 
     if (tid < QB) badq[tid] = 0;
-    __syncthreads();
-    // NaN / Inf in a query vector (Coding.java:356-361): flagged here, the sums below simply carry the NaN
-    for (int idx = tid; idx < QB * d; idx += kEncThreads) {
-        const int qq = idx / d, i = idx - qq * d;
-        const int64_t qi = q0 + qq;
-        if (qi < nq && !(fabs(static_cast<double>(q[qi * d + i])) <= 1.79769313486231570815e+308)) atomicOr(&badq[qq], 1);
+    // NaN / Inf in a query vector (Coding.java:356-361): every thread fetches its share of the QB rows NOW and looks at it
+    // after the projection loop, so this round trip is hidden behind the loop (the sums simply carry a NaN)
+    constexpr int kChk = 4;                       // elements per thread kept in registers; longer rows are checked in place
+    TIn chk[kChk];
+#pragma unroll
+    for (int u = 0; u < kChk; u++) {
+        const int idx = tid + u * kEncThreads;
+        const int qq = idx / d;
+        chk[u] = (idx < QB * d && q0 + qq < nq) ? q[(q0 + qq) * d + (idx - qq * d)] : TIn(0);
     }
 
     double acc[QB];
@@ -78,6 +81,17 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
         }
     }
 
+    __syncthreads();                                  // badq[] is zero
+#pragma unroll
+    for (int u = 0; u < kChk; u++) {
+        const int idx = tid + u * kEncThreads;
+        if (idx < QB * d && !(fabs(static_cast<double>(chk[u])) <= 1.79769313486231570815e+308)) atomicOr(&badq[idx / d], 1);
+    }
+    for (int idx = tid + kChk * kEncThreads; idx < QB * d; idx += kEncThreads) {
+        const int qq = idx / d, i = idx - qq * d;
+        const int64_t qi = q0 + qq;
+        if (qi < nq && !(fabs(static_cast<double>(q[qi * d + i])) <= 1.79769313486231570815e+308)) atomicOr(&badq[qq], 1);
+    }
     if (active) {
         const double rr = r[p], ww = omega[p];
 #pragma unroll
