@@ -462,18 +462,13 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
                 e0 += cnt;
             }
             __syncthreads();
+            // classify only: the global result stores come last (a workgroup barrier waits for outstanding stores, so a
+            // store followed by a barrier costs a full HBM write latency in the middle of the query)
             for (int i = tid; i < nsel; i += nthreads) {
                 const int lt = lrank[i];
-                const uint64_t e = ht[ulist[i]];
-                const int32_t id = static_cast<int32_t>(e >> 32);
-                if (rk[lt] == 1) {
-                    if (lt < nout) {
-                        prm.out_ids[qi * prm.out_cap + lt] = id;
-                        if (prm.out_score) prm.out_score[qi * prm.out_cap + lt] = static_cast<int32_t>(static_cast<uint32_t>(e) >> kBucketBits);
-                    }
-                } else {   // shares (score, bucket) with another entry: settled below by insertion sequence
+                if (rk[lt] != 1) {   // shares (score, bucket) with another entry: settled below by insertion sequence
                     const int c = atomicAdd(&s_ncoll, 1);
-                    if (c < kLzCollMax) { c_elem[c] = i; c_lt[c] = lt; c_id[c] = id; c_seq[c] = 0x7FFFFFFF; }
+                    if (c < kLzCollMax) { c_elem[c] = i; c_lt[c] = lt; c_id[c] = static_cast<int32_t>(ht[ulist[i]] >> 32); c_seq[c] = 0x7FFFFFFF; }
                 }
             }
             __syncthreads();
@@ -482,40 +477,51 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             if (tid == 0 && prm.dbg && qi == blockIdx.x) { prm.dbg[blockIdx.x * 16 + 13] = ncoll; prm.dbg[blockIdx.x * 16 + 15] = nsel; prm.dbg[blockIdx.x * 16 + 14] = dbg_outer | (dbg_inner << 8) | (dbg_reload << 16) | (static_cast<long long>(dbg_nitb) << 24); }
             if (ncoll > kLzCollMax) {
                 overflow = true;
-            } else if (ncoll > 0) {
-                // ---- 4. reference insertion sequence of the colliding entries: one (entry, table) pair per thread, the
-                // inverse-map loads of up to four pairs in flight together ----
-                const int npair = ncoll * TD;
-                for (int t0 = tid; t0 < npair; t0 += nthreads * 4) {
-                    int32_t idxv[4];
+            } else {
+                if (ncoll > 0) {
+                    // ---- 4. reference insertion sequence of the colliding entries: one (entry, table) pair per thread, the
+                    // inverse-map loads of up to four pairs in flight together ----
+                    const int npair = ncoll * TD;
+                    for (int t0 = tid; t0 < npair; t0 += nthreads * 4) {
+                        int32_t idxv[4];
 #pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const int t = t0 + v * nthreads;
-                        idxv[v] = (t < npair) ? prm.inv[static_cast<int64_t>(t % TD) * prm.n_ids + c_id[t / TD]] : -1;
+                        for (int v = 0; v < 4; v++) {
+                            const int t = t0 + v * nthreads;
+                            idxv[v] = (t < npair) ? prm.inv[static_cast<int64_t>(t % TD) * prm.n_ids + c_id[t / TD]] : -1;
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; v++) {
+                            const int t = t0 + v * nthreads;
+                            const int32_t idx = idxv[v];
+                            if (idx < 0) continue;
+                            const int c = t / TD, td = t - c * TD;
+                            for (int step = 0; step < P; step++) {
+                                const int4 e = plist[td * P + step];
+                                if (e.x >= 0 && idx >= e.z && idx < e.z + e.w) { atomicMin(&c_seq[c], (td * P + step) * S + (idx - e.z)); break; }
+                            }
+                        }
                     }
-#pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        const int t = t0 + v * nthreads;
-                        const int32_t idx = idxv[v];
-                        if (idx < 0) continue;
-                        const int c = t / TD, td = t - c * TD;
-                        for (int step = 0; step < P; step++) {
-                            const int4 e = plist[td * P + step];
-                            if (e.x >= 0 && idx >= e.z && idx < e.z + e.w) { atomicMin(&c_seq[c], (td * P + step) * S + (idx - e.z)); break; }
+                    for (int c = tid; c < ncoll; c += nthreads) c_elem[c] = static_cast<int32_t>(pre[c_elem[c]]);   // element -> its key
+                    __syncthreads();
+                    for (int c = tid; c < ncoll; c += nthreads) {
+                        const int32_t my = c_elem[c];
+                        const int myseq = c_seq[c];
+                        int rank = c_lt[c];
+#pragma unroll 4
+                        for (int c2 = 0; c2 < ncoll; c2++) rank += (c_elem[c2] == my) && (c_seq[c2] < myseq);
+                        if (rank < nout) {
+                            prm.out_ids[qi * prm.out_cap + rank] = c_id[c];
+                            if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = static_cast<int32_t>(static_cast<uint32_t>(my) >> kBucketBits);
                         }
                     }
                 }
-                for (int c = tid; c < ncoll; c += nthreads) c_elem[c] = static_cast<int32_t>(pre[c_elem[c]]);   // element -> its key
-                __syncthreads();
-                for (int c = tid; c < ncoll; c += nthreads) {
-                    const int32_t my = c_elem[c];
-                    const int myseq = c_seq[c];
-                    int rank = c_lt[c];
-#pragma unroll 4
-                    for (int c2 = 0; c2 < ncoll; c2++) rank += (c_elem[c2] == my) && (c_seq[c2] < myseq);
-                    if (rank < nout) {
-                        prm.out_ids[qi * prm.out_cap + rank] = c_id[c];
-                        if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = static_cast<int32_t>(static_cast<uint32_t>(my) >> kBucketBits);
+                // ---- results of the entries with a key of their own ----
+                for (int i = tid; i < nsel; i += nthreads) {
+                    const int lt = lrank[i];
+                    if (lt < nout && rk[lt] == 1) {
+                        const uint64_t e = ht[ulist[i]];
+                        prm.out_ids[qi * prm.out_cap + lt] = static_cast<int32_t>(e >> 32);
+                        if (prm.out_score) prm.out_score[qi * prm.out_cap + lt] = static_cast<int32_t>(static_cast<uint32_t>(e) >> kBucketBits);
                     }
                 }
             }
@@ -527,6 +533,11 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
                 for (int i = tid; i < TD; i += nthreads) nprobe_in[qi * TD + i] = nprobe_l[i];
             }
             if (tid == 0) prm.ovf_list[atomicAdd(prm.ovf_count, 1)] = static_cast<int32_t>(qi);
+        }
+        if (qi + gridDim.x >= prm.nq) {   // last query of this workgroup: nothing to tidy up, the stores drain on their own
+            LZ_STAMP(6);
+            LZ_STAMP(7);
+            break;
         }
         __syncthreads();
         LZ_STAMP(6);
