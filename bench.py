@@ -428,6 +428,20 @@ def main():
                    sample=f"{ns} queries x {reps} passes of the same batch (encode + Route + Refine on plaintext, "
                           f"no AES/RocksDB), C++ oracle single thread; host has {os.cpu_count()} logical cores",
                    matches_gpu=same)
+        # the same port over the host cores this GPU's share allows (queries are independent: threads over queries)
+        nthr = max(1, min(16, os.cpu_count() or 1))
+        if nthr > 1:
+            t2 = time.perf_counter()
+            reps2, done2 = 0, 0
+            while True:
+                cds = o.encode(qs)
+                o.search(qs, k, codes=cds, threads=nthr)
+                reps2 += 1
+                done2 += ns
+                if time.perf_counter() - t2 > 5.0 or reps2 >= 200:
+                    break
+            cpu["multi_thread"] = dict(value=round(done2 / (time.perf_counter() - t2), 1), unit="queries/s", cores=nthr,
+                                       note="Route + Refine threaded over queries, encode single-threaded")
 
     if rank == 0:
         out = {
