@@ -57,9 +57,10 @@ def main():
     ap.add_argument("--query-batches", type=int, default=8,
                     help="distinct query batches cycled through by the steps (a repeated batch would re-read the same "
                          "candidate rows out of the 256 MiB Infinity Cache instead of HBM)")
-    ap.add_argument("--merge", default="inline", choices=["inline", "overlap"],
+    ap.add_argument("--merge", default="auto", choices=["auto", "inline", "overlap"],
                     help="N > 1: the RCCL all-gather of the per-rank top-k follows Refine on the same stream (inline), or runs on "
-                         "a side stream overlapping the next step (overlap; costs two cross-stream events per step)")
+                         "a side stream overlapping the next step (overlap; costs two cross-stream events per step). auto: both "
+                         "are tried for a few untimed steps before the warmup and the faster one is used by every rank")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream pass reported under 'pipelined'")
     ap.add_argument("--route-counters", action="store_true",
                     help="also produce lastCandKept / rawSeen per query (forces the full select)")
@@ -188,7 +189,7 @@ def main():
     streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
     F32 = pkg._native.F32
     step_no = [0]
-    inline_merge = (args.merge == "inline")
+    merge_mode = [args.merge if args.merge != "auto" else "inline"]   # "inline" | "overlap"; "auto" is settled before the warmup
     # QSI's adaptive retry (QSI:327-337,444-447): one more pass with 10 probes when returned < K or decrypted < 10*K.
     # With B < 10*K the second condition always holds (decrypted <= B), so every query takes both passes and the second
     # one is the answer; with B >= 10*K (and >= K finite candidates, true for the synthetic data) it never triggers.
@@ -209,13 +210,13 @@ def main():
             # the whole step in ONE library call (encode -> route(limit = B) -> refine from the store, stream order)
             par = b["nsteps"] & 1
             b["nsteps"] += 1
-            if use_dist and b["nsteps"] > 2 and not inline_merge:
+            if use_dist and b["nsteps"] > 2 and merge_mode[0] != "inline":
                 b["ev_gath"][par].wait(stream)            # the all-gather that last read this result buffer has finished
             for pov in probe_passes:
                 cx.search_store_dev(Q, qp, F32, pov, B, k, b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(),
                                     b["out_cnt"].data_ptr(), b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(),
                                     b["bad"].data_ptr())
-            if use_dist and inline_merge:
+            if use_dist and merge_mode[0] == "inline":
                 # the collective follows Refine on the SAME stream: no cross-stream events (each costs this stream two
                 # extra barrier packets, ~20 us per step on this runtime — more than the all-gather itself)
                 merge(b["topk"][par], b["gathered"][par], stream)
@@ -247,7 +248,7 @@ def main():
             events[3].record(stream)
         par = b["nsteps"] & 1
         b["nsteps"] += 1
-        if use_dist and b["nsteps"] > 2 and not inline_merge:
+        if use_dist and b["nsteps"] > 2 and merge_mode[0] != "inline":
             b["ev_gath"][par].wait(stream)            # the all-gather that last read this result buffer has finished
         if dense:
             cx.refine_dev(Q, qp, F32, b["cand"].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
@@ -258,7 +259,7 @@ def main():
                                 b["scored"].data_ptr())
         if events is not None:
             events[4].record(stream)
-        if use_dist and inline_merge:
+        if use_dist and merge_mode[0] == "inline":
             merge(b["topk"][par], b["gathered"][par], stream)
         elif use_dist:
             # --merge overlap: the all-gather of [Q x k] (id, dist) per rank on a side stream, so that it overlaps the
@@ -274,6 +275,31 @@ def main():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
+
+    # --merge auto: which placement of the collective is faster depends on the all-gather latency of this node (ranks,
+    # xGMI hops) against the fixed cost of two cross-stream events; a short untimed trial decides, rank 0's verdict holds
+    merge_trial = None
+    if use_dist and args.merge == "auto":
+        trial = {}
+        for mode in ("inline", "overlap"):
+            merge_mode[0] = mode
+            for b_ in bufs:
+                b_["nsteps"] = 0
+            for _ in range(4):
+                step()
+            barrier()
+            t_t = time.perf_counter()
+            for _ in range(12):
+                step()
+            barrier()
+            trial[mode] = (time.perf_counter() - t_t) / 12
+        tt = torch.tensor([trial["inline"], trial["overlap"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)                     # slowest rank per mode
+        merge_mode[0] = "inline" if float(tt[0]) <= float(tt[1]) else "overlap"
+        merge_trial = "inline %.1f us/step, overlap %.1f us/step" % (float(tt[0]) * 1e6, float(tt[1]) * 1e6)
+        for b_ in bufs:
+            b_["nsteps"] = 0
+        barrier()
 
     for _ in range(args.warmup):
         step()
@@ -459,7 +485,7 @@ def main():
             "data": "synthetic N(0,1) fp32 vectors (SIFT-1M shape), exact-kNN ground truth of the synthetic set",
             "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
                        "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "distinct_query_batches": NB, "route_counters": bool(args.route_counters), "passes_per_step": len(probe_passes),
-                       "parallelism": f"query-sharded x{world}, index replicated", "merge": (gather_path + (", same stream" if inline_merge else ", side stream")) if use_dist else None, "streams_per_gpu": active[0],
+                       "parallelism": f"query-sharded x{world}, index replicated", "merge": (gather_path + (", same stream" if merge_mode[0] == "inline" else ", side stream") + (" (auto: %s)" % merge_trial if merge_trial else "")) if use_dist else None, "streams_per_gpu": active[0],
                        "candidates": "rows read from the HBM-resident plaintext store by id inside the refine scan" if not dense
                        else "rows packed into [Q][B][d] by a gather kernel (host decrypt stand-in), then scanned"},
             "recall_at_10": recall,
