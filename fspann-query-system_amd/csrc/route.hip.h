@@ -334,6 +334,8 @@ template <bool kLds, int kThreads>
 __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams prm, const int4* __restrict__ probe_in,
                                                                 const int32_t* __restrict__ nprobe_in) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // list mode (hand-back of the bounded select): normally the list is empty — leave before anything else is touched
+    if (prm.qlist && *prm.qcount == 0) return;
     const int tid = threadIdx.x;
     constexpr int nthreads = kThreads;
     const int lane = tid & 63, wave = tid >> 6;
