@@ -6,7 +6,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(20))
+import os
+
+N_SEEDS = int(os.environ.get("FSPANN_FUZZ_SEEDS", "20"))
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_refine(pkg, oracle, seed):
     rng = np.random.default_rng(500 + seed)
     B = int(rng.choice([1, 7, 64, 255, 256, 257, 512, 700, 1100]))

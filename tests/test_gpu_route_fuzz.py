@@ -9,7 +9,12 @@ from test_gpu_route_edges import LAZY_RUNS, check_route
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(24))
+import os
+
+N_SEEDS = int(os.environ.get("FSPANN_FUZZ_SEEDS", "24"))     # FSPANN_FUZZ_SEEDS=300 for a long run
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_scene(pkg, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     T = int(rng.integers(1, 9))
