@@ -308,9 +308,9 @@ def main():
     evs = [[ev() for _ in range(5)] for _ in range(args.steps)]
     barrier()
     t_start = time.perf_counter()
-    # timed region: every 5th refinement-scan dispatch carries its own start/stop HIP events (kernel-attached, on the
+    # timed region: every TIMED_EVERY-th refinement-scan dispatch carries its own start/stop HIP events (kernel-attached, on the
     # context's stream) -> roofline.  (An attached pair costs a few us of stream time, so not every dispatch gets one.)
-    TIMED_EVERY = 5
+    TIMED_EVERY = max(2, args.steps // 8)     # about eight timed dispatches whatever --steps is
     for c_ in ctxs[:active[0]]:
         c_.refine_timing_begin(args.steps, TIMED_EVERY)
     for i in range(args.steps):
