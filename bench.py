@@ -47,8 +47,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="sift1m_T16_b32_B256_Q1024", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -19,3 +19,14 @@ def run(reps):
 run(40); ctx.sync()
 t0 = time.perf_counter(); run(400); ctx.sync(); t1 = time.perf_counter()
 print("%.2f us/step  %.2f M queries/s" % (1e6 * (t1 - t0) / 400, Q * 400 / (t1 - t0) / 1e6))
+ctx.refine_timing_begin(400, 6)
+t0 = time.perf_counter(); run(400); ctx.sync(); t1 = time.perf_counter()
+nl, ms = ctx.refine_timing_end()
+print("with kernel-attached events on every 6th refine dispatch: %.2f us/step (%d timed, avg %.2f us)" % (1e6 * (t1 - t0) / 400, nl, 1e3 * ms / max(nl, 1)))
+sel = torch.zeros((Q, B), dtype=torch.int32, device=dev); selc = torch.zeros(Q, dtype=torch.int32, device=dev); sc = torch.zeros(Q, dtype=torch.int32, device=dev); bad = torch.zeros(Q, dtype=torch.int32, device=dev)
+def run2(reps):
+    for i in range(reps):
+        ctx.search_store_dev(Q, qs[i % 8].data_ptr(), F32, -1, B, k, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), sc.data_ptr(), sel.data_ptr(), selc.data_ptr(), bad.data_ptr())
+run2(20); ctx.sync()
+t0 = time.perf_counter(); run2(400); ctx.sync(); t1 = time.perf_counter()
+print("with the optional outputs: %.2f us/step" % (1e6 * (t1 - t0) / 400))
