@@ -114,7 +114,14 @@ public final class GpuRouteRefine implements AutoCloseable {
     public static final class Routed { public String[] ids; public long[] score; public int kept, rawSeen; }
 
     /** PIS.lookupCandidatesWithScores (limit = Integer.MAX_VALUE) / QSI stage A.5 (limit = refinementLimit). */
-    public Routed route(BitSet[][] codes, int probeOverride, int limit) {
+    public Routed route(BitSet[][] codes, int probeOverride, int limit) { return route(codes, probeOverride, limit, true); }
+
+    /**
+     * withCounters = false: lastCandKept / rawSeen are not produced (kept = rawSeen = -1) and the library may run its
+     * bounded select — the same first {@code limit} entries, about 3x faster at limit = 256.  Use it whenever the
+     * profiler columns candKept / candTotal are not being recorded.
+     */
+    public Routed route(BitSet[][] codes, int probeOverride, int limit, boolean withCounters) {
         int TD = tables * divisions;
         ByteBuffer c = buf(8L * TD * words);
         for (int t = 0; t < tables; t++)
@@ -123,15 +130,16 @@ public final class GpuRouteRefine implements AutoCloseable {
                 for (int k = 0; k < words; k++) c.putLong(k < w.length ? w[k] : 0L);
             }
         long cap = Math.min(limit, FspannNative.routeMaxCandidates(ctx, probeOverride));
-        ByteBuffer ids = buf(4 * cap), sc = buf(4 * cap), cnt = buf(4), kept = buf(4), raw = buf(4);
+        ByteBuffer ids = buf(4 * cap), sc = buf(4 * cap), cnt = buf(4);
+        ByteBuffer kept = withCounters ? buf(4) : null, raw = withCounters ? buf(4) : null;
         FspannNative.check(FspannNative.route(ctx, 1, c, probeOverride, limit, cap, ids, sc, cnt, kept, raw));
         Routed r = new Routed();
         int n = cnt.getInt(0);
         r.ids = new String[n];
         r.score = new long[n];
         for (int i = 0; i < n; i++) { r.ids[i] = idOf.get(ids.getInt(4 * i)); r.score[i] = sc.getInt(4 * i); }
-        r.kept = kept.getInt(0);
-        r.rawSeen = raw.getInt(0);
+        r.kept = withCounters ? kept.getInt(0) : -1;
+        r.rawSeen = withCounters ? raw.getInt(0) : -1;
         return r;
     }
 
