@@ -430,9 +430,13 @@ def main():
         a, r_, w_ = ctx.get_gfunctions()
         o.set_gfunctions(a, r_, w_)
         o.set_id_meta(n)
-        for td in range(TD):
-            o.set_index(td, **ctx.get_index(td))
-        o.set_store(X.astype(np.float64))
+        X64 = X.astype(np.float64)
+        o.set_store(X64)
+        t_ob = time.perf_counter()
+        o.build_index(X64)                     # the checker cuts its OWN partitions (nothing imported from the GPU build)
+        t_ob = time.perf_counter() - t_ob
+        del X64
+        index_same = all(np.array_equal(ctx.get_index(td)[k_], v_) for td in range(TD) for k_, v_ in o.get_index(td).items())
         ns = min(args.cpu_sample, Q)
         qs = Qh[:ns].astype(np.float64)
         t1 = time.perf_counter()
@@ -450,10 +454,15 @@ def main():
         cpu_s = time.perf_counter() - t1
         same = bool(np.array_equal(ref["ids"], out_ids.cpu().numpy()[:ns]) and
                     np.array_equal(ref["dist"], out_dist.cpu().numpy()[:ns]))
+        if o.unmodelled:
+            raise SystemExit("bench: a HashMap bin treeified in the oracle at this workload: the checker has no pinned order")
+        if not (same and index_same):
+            raise SystemExit(f"bench: GPU results differ from the CPU oracle (index_same={index_same}, results_same={same})")
         cpu = dict(value=round(done / cpu_s, 1), unit="queries/s", cores=1, kind="port",
                    sample=f"{ns} queries x {reps} passes of the same batch (encode + Route + Refine on plaintext, "
                           f"no AES/RocksDB), C++ oracle single thread; host has {os.cpu_count()} logical cores",
-                   matches_gpu=same)
+                   matches_gpu=same, index_matches_gpu=bool(index_same), oracle_unmodelled=bool(o.unmodelled),
+                   oracle_index_build_s=round(t_ob, 1))
         # the same port over the host cores this GPU's share allows (queries are independent: threads over queries)
         nthr = max(1, min(16, os.cpu_count() or 1))
         if nthr > 1:

@@ -113,6 +113,7 @@ _SIGS = {
     "fspann_effective_probes": (_i, [_vp, _i]),
     "fspann_set_route_mode": (_i, [_vp, _i]),
     "fspann_last_route_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "fspann_unmodelled_queries": (_i, [_vp, C.POINTER(_i64), _i]),
     "fspann_refine": (_i, [_vp, _i64, _vp, _vp, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "fspann_refine_dev": (_i, [_vp, _i64, _vp, _i, _vp, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "fspann_refine_store": (_i, [_vp, _i64, _vp, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -54,6 +54,38 @@ int upload_index(fspann_ctx* c) {
     const int TD = c->TD, W = c->W;
     for (int td = 0; td < TD; td++)
         if (!c->h_table_set[td]) return fail(FSPANN_E_STATE, "table %d was never set (fspann_set_index)", td);
+    // Every handle of every table must lie in [0, n_ids) — the kernels index java_hash / deleted_bits / the store with it —
+    // and occur at most once per table (a division's HashMap holds an id once, PIS:331-346; the select kernels rely on it).
+    // Checked here rather than in fspann_set_index because the documented import order sets the tables before the id metadata.
+    {
+        std::atomic<int> bad_td{-1}, bad_kind{0};
+        std::atomic<long long> bad_id{0};
+        std::atomic<bool> oom{false};
+        const int nthv = std::max(1, std::min<int>(TD, static_cast<int>(std::thread::hardware_concurrency())));
+        std::vector<std::thread> thv;
+        for (int w = 0; w < nthv; w++)
+            thv.emplace_back([&, w] {
+                try {
+                    std::vector<uint64_t> seen(static_cast<size_t>((c->n_ids + 63) / 64));
+                    for (int td = w; td < TD && bad_td.load() < 0; td += nthv) {
+                        std::fill(seen.begin(), seen.end(), 0ull);
+                        for (const int32_t id : c->h_ids[td]) {
+                            int kind = 0;
+                            if (id < 0 || id >= c->n_ids) kind = 1;
+                            else if ((seen[static_cast<size_t>(id) >> 6] >> (id & 63)) & 1ull) kind = 2;
+                            if (kind) { bad_td = td; bad_kind = kind; bad_id = id; return; }
+                            seen[static_cast<size_t>(id) >> 6] |= 1ull << (id & 63);
+                        }
+                    }
+                } catch (...) { oom = true; }
+            });
+        for (auto& t : thv) t.join();
+        if (oom) return fail(FSPANN_E_NOMEM, "out of host memory");
+        if (bad_td.load() >= 0)
+            return bad_kind.load() == 1
+                       ? fail(FSPANN_E_ARG, "table %d: id handle %lld out of range [0,%lld)", bad_td.load(), bad_id.load(), (long long)c->n_ids)
+                       : fail(FSPANN_E_ARG, "table %d holds id handle %lld twice", bad_td.load(), bad_id.load());
+    }
     c->h_tables.assign(TD, RouteTable{});
     int64_t parts = 0, offs = 0, ids = 0;
     for (int td = 0; td < TD; td++) {
@@ -110,6 +142,7 @@ int upload_index(fspann_ctx* c) {
         const int nth = std::max(1, std::min<int>(TD, static_cast<int>(std::thread::hardware_concurrency())));
         for (int w = 0; w < nth; w++)
             th.emplace_back([&, w] {
+              try {
                 std::vector<uint64_t> tmp;
                 for (int td = w; td < TD; td += nth) {
                     int32_t* row = inv.data() + static_cast<size_t>(td) * static_cast<size_t>(c->n_ids);
@@ -134,6 +167,7 @@ int upload_index(fspann_ctx* c) {
                             bk[static_cast<size_t>(t.ids_base + b0) + j] = (static_cast<uint64_t>(static_cast<uint32_t>(tmp[j])) << 32) | (tmp[j] >> 44);
                     }
                 }
+              } catch (...) { ok = false; }   // out of host memory: the bounded select stays off
             });
         for (auto& t : th) t.join();
         if (ok) {
@@ -234,17 +268,13 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     pl.need_cap = (mt >= c->hard_cap) ? 1 : 0;
     pl.maxcand = static_cast<int>(std::min<int64_t>(mt, static_cast<int64_t>(c->hard_cap) - 1 + pl.S));
     // B1 inserts every tuple (also those behind a HARD_CAP cut): size for max_tuples, load factor <= 0.5
-    {   // load factor: <= 0.8 by default (2 workgroups per CU at BASELINE config #2); FSPANN_ROUTE_HT_X4=1 -> <= 0.5
-        const char* e = getenv("FSPANN_ROUTE_HT_X4");
-        const int64_t want = (e && e[0] == '1') ? static_cast<int64_t>(pl.max_tuples) * 2 : static_cast<int64_t>(pl.max_tuples) + pl.max_tuples / 4;
+    {   // load factor: <= 0.8 by default (2 workgroups per CU at BASELINE config #2); knob_ht_x4 -> <= 0.5
+        const int64_t want = c->knob_ht_x4 ? static_cast<int64_t>(pl.max_tuples) * 2 : static_cast<int64_t>(pl.max_tuples) + pl.max_tuples / 4;
         pl.ht_size = std::max(64, next_pow2(want));
     }
     pl.ht_shift = 32 - __builtin_ctz(pl.ht_size);
     pl.nbins = c->bits + 1;
-    {
-        const char* e = getenv("FSPANN_ROUTE_THREADS");
-        pl.threads = (e && atoi(e) == 1024) ? 1024 : 512;
-    }
+    pl.threads = c->knob_threads;
     const int full_sort = next_pow2(std::max(pl.maxcand, 1));
     pl.sort_cap = std::min(full_sort, 1024);
     const size_t TP = static_cast<size_t>(c->TD) * pl.P;
@@ -271,8 +301,7 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     const bool cap_fixed = java_final_cap_host(c->cap0, mt) == c->cap0;       // HashMap never resizes
     const bool legal = c->d_inv && c->d_ids_bk && c->bk_epoch == c->meta_epoch && !pl.need_cap && cap_fixed && !want_counters && limit <= 512 && pl.lds_mode;
     if (legal && c->route_mode != 1 && (c->route_mode == 2 || static_cast<int64_t>(limit) * 4 <= mt)) {
-        const char* ce = getenv("FSPANN_ROUTE_LAZY_CAP");   // tests: distinct ids one query may hold before it is handed back
-        const int cap_env = ce ? atoi(ce) : 0;
+        const int cap_env = c->knob_lazy_cap;   // tests: distinct ids one query may hold before it is handed back
         const size_t lds = static_cast<size_t>(kLzHtSize) * 8 + TP * 16 + 4096 + 4096 + (TP + 2) * 8 + (TP + 1) * 4 + 8 +
                            static_cast<size_t>(c->TD) * 8 + ((TP * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kLzEntries) * 2 + 4096 + static_cast<size_t>(c->TD) * 4 + 16;
         if (TP < 32768 && lds <= budget) {
@@ -343,10 +372,24 @@ int launch_refine_t(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int6
                     const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist, int32_t* out_count,
                     int32_t* scored) {
     constexpr int DC0 = (sizeof(TC) == 4) ? 32 : 16;
-    static const int dc_env = [] { const char* e = getenv("FSPANN_REFINE_DC"); return e ? atoi(e) : 0; }();
+    const int dc_env = c->knob_refine_dc;
     if (dc_env == DC0 * 2) return launch_refine_dc<TC, TQ, DC0 * 2, GATHER>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
     if (dc_env == DC0 * 4) return launch_refine_dc<TC, TQ, DC0 * 4, GATHER>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
     return launch_refine_dc<TC, TQ, DC0, GATHER>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
+}
+
+// No C++ exception crosses the C ABI (include/fspann.h): every entry point that allocates host memory or starts
+// threads runs its body through guarded(); worker threads catch on their own and report through a flag.
+template <class F> int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(FSPANN_E_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(FSPANN_E_ARG, "C++ exception: %s", e.what());
+    } catch (...) {
+        return fail(FSPANN_E_ARG, "unknown C++ exception");
+    }
 }
 
 #define CHECK_CTX(c)                                                      \
@@ -414,8 +457,20 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         delete c;
         return fail(FSPANN_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    {   // tuning / test knobs: read once per context, never on the call path
+        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; };
+        c->knob_ht_x4 = env_int("FSPANN_ROUTE_HT_X4", 0) == 1;
+        c->knob_threads = env_int("FSPANN_ROUTE_THREADS", 512) == 1024 ? 1024 : 512;
+        c->knob_lazy_cap = std::max(0, env_int("FSPANN_ROUTE_LAZY_CAP", 0));
+        c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
+        c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
+    }
     c->h_min.resize(c->TD); c->h_max.resize(c->TD); c->h_off.resize(c->TD); c->h_rep.resize(c->TD); c->h_ids.resize(c->TD);
     c->h_table_set.assign(c->TD, 0);
+    if (hipMalloc(&c->d_unmodelled, 256) != hipSuccess || hipMemset(c->d_unmodelled, 0, 256) != hipSuccess) {
+        fspann_ctx_destroy(c);
+        return fail(FSPANN_E_NOMEM, "hipMalloc failed");
+    }
     *out = c;
     return FSPANN_OK;
 }
@@ -426,7 +481,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_dev(c->ws_fix.p);
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
-    free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
+    free_devt(c->d_java_hash); free_devt(c->d_deleted_bits); free_devt(c->d_unmodelled);
     free_dev(c->d_store);
     free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
@@ -449,6 +504,7 @@ int fspann_set_gfunctions(fspann_ctx* c, const double* alpha, const double* r, c
     const int P = c->P_total, d = c->cfg.dim;
     for (int p = 0; p < P; p++)
         if (!(omega[p] > 0.0)) return fail(FSPANN_E_ARG, "omega_j <= 0");  // Coding.java:84-86
+    return guarded([&]() -> int {
     std::vector<double> aT(static_cast<size_t>(d) * P);
     for (int p = 0; p < P; p++)
         for (int i = 0; i < d; i++) aT[static_cast<size_t>(i) * P + p] = alpha[static_cast<size_t>(p) * d + i];
@@ -475,6 +531,7 @@ int fspann_set_gfunctions(fspann_ctx* c, const double* alpha, const double* r, c
     if (c->h_alpha.data() != alpha) { c->h_alpha.assign(alpha, alpha + static_cast<size_t>(P) * d); c->h_r.assign(r, r + P); c->h_omega.assign(omega, omega + P); }
     c->have_g = true;
     return FSPANN_OK;
+    });
 }
 
 // GFunctionRegistry.initialize (idx/GFunctionRegistry.java:63-147) = T*D x Coding.buildFromSample
@@ -486,6 +543,7 @@ int fspann_registry_initialize(fspann_ctx* c, const double* sample, int64_t ns, 
     if (!sample) return fail(FSPANN_E_NULL, "sample");
     if (ns <= 0) return fail(FSPANN_E_ARG, "Sample vectors cannot be empty");
     const int TD = c->TD, m = c->cfg.m, d = c->cfg.dim, P = c->P_total, D = c->cfg.divisions;
+    return guarded([&]() -> int {
     struct Rng {
         uint64_t s;
         uint64_t nextLong() {
@@ -554,6 +612,7 @@ int fspann_registry_initialize(fspann_ctx* c, const double* sample, int64_t ns, 
     c->h_alpha = alpha; c->h_r = r; c->h_omega = w;
     rc = fspann_set_gfunctions(c, alpha.data(), r.data(), w.data());
     return rc;
+    });
 }
 
 int fspann_get_gfunctions(fspann_ctx* c, double* alpha, double* r, double* omega) {
@@ -579,9 +638,9 @@ int fspann_set_index(fspann_ctx* c, int td, int64_t n_parts, const int64_t* min_
     }
     const int64_t nid = n_parts > 0 ? id_off[n_parts] : 0;
     if (nid >= (1LL << 31)) return fail(FSPANN_E_RANGE, "table has >= 2^31 ids");
-    if (c->n_ids > 0)
-        for (int64_t i = 0; i < nid; i++)
-            if (ids[i] < 0 || ids[i] >= c->n_ids) return fail(FSPANN_E_ARG, "id handle %d out of range [0,%lld)", ids[i], (long long)c->n_ids);
+    // id handles are validated against n_ids by fspann_finalize (the id metadata may arrive after the tables)
+    c->frozen = false;
+    return guarded([&]() -> int {
     c->h_min[td].assign(min_key, min_key + n_parts);
     c->h_max[td].assign(max_key, max_key + n_parts);
     c->h_rep[td].assign(rep, rep + n_parts * c->W);
@@ -590,11 +649,14 @@ int fspann_set_index(fspann_ctx* c, int td, int64_t n_parts, const int64_t* min_
     c->h_table_set[td] = 1;
     c->dev_index_dirty = true;
     return FSPANN_OK;
+    });
 }
 
 int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, const uint8_t* deleted) {
     CHECK_CTX(c);
     if (n_ids <= 0 || n_ids >= (1LL << 31)) return fail(FSPANN_E_ARG, "n_ids out of range");
+    c->frozen = false;           // Route stays off until the next successful fspann_finalize re-validates every table
+    return guarded([&]() -> int {
     c->h_java_hash.resize(static_cast<size_t>(n_ids));
     c->decimal_ids = (java_hash == nullptr);
     if (java_hash) std::copy(java_hash, java_hash + n_ids, c->h_java_hash.begin());
@@ -616,6 +678,7 @@ int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, c
     c->dev_index_dirty = true;
     c->n_ids = n_ids;
     return FSPANN_OK;
+    });
 }
 
 int fspann_finalize(fspann_ctx* c) {
@@ -623,7 +686,8 @@ int fspann_finalize(fspann_ctx* c) {
     if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized");
     if (c->n_ids <= 0) return fail(FSPANN_E_STATE, "id metadata not set (fspann_set_id_meta)");
     if (c->dev_index_dirty) {
-        int rc = upload_index(c);
+        c->frozen = false;
+        int rc = guarded([&]() -> int { return upload_index(c); });
         if (rc) return rc;
     }
     c->frozen = true;
@@ -648,6 +712,8 @@ int fspann_index_save(fspann_ctx* c, const char* path) {
     if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
     FILE* f = std::fopen(path, "wb");
     if (!f) return fail(FSPANN_E_ARG, "cannot open %s for writing", path);
+    struct Closer { FILE*& f; ~Closer() { if (f) std::fclose(f); } } closer{f};
+    return guarded([&]() -> int {
     bool ok = true;
     const char magic[8] = {'F', 'S', 'P', 'A', 'N', 'N', 'I', 'X'};
     const uint32_t ver = 1;
@@ -669,7 +735,9 @@ int fspann_index_save(fspann_ctx* c, const char* path) {
              wr(f, c->h_rep[td].data(), c->h_rep[td].size()) && wr(f, c->h_off[td].data(), c->h_off[td].size()) && wr(f, c->h_ids[td].data(), ni);
     }
     ok = (std::fclose(f) == 0) && ok;
+    f = nullptr;
     return ok ? FSPANN_OK : fail(FSPANN_E_ARG, "short write to %s", path);
+    });
 }
 
 int fspann_index_load(fspann_ctx* c, const char* path) {
@@ -678,6 +746,14 @@ int fspann_index_load(fspann_ctx* c, const char* path) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(FSPANN_E_ARG, "cannot open %s", path);
     struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+    // whatever happens below, the context serves no Route until a finalize has succeeded on the new state
+    c->frozen = false;
+    return guarded([&]() -> int {
+    // every count read from the file is checked against the bytes the file still holds BEFORE anything is sized from it
+    if (std::fseek(f, 0, SEEK_END) != 0) return fail(FSPANN_E_ARG, "cannot seek in %s", path);
+    const long long fsize = std::ftell(f);
+    std::rewind(f);
+    auto left = [&]() -> long long { return fsize - std::ftell(f); };
     char magic[8];
     uint32_t ver = 0;
     int32_t hdr[6];
@@ -692,6 +768,7 @@ int fspann_index_load(fspann_ctx* c, const char* path) {
                     hdr[2], hdr[3], hdr[4]);
     if (n_ids <= 0 || n_ids >= (1LL << 31)) return fail(FSPANN_E_ARG, "bad n_ids in %s", path);
     const size_t P = static_cast<size_t>(c->P_total), d = static_cast<size_t>(c->cfg.dim);
+    if (static_cast<long long>((P * d + 2 * P) * 8) + n_ids * 5 > left()) return fail(FSPANN_E_ARG, "truncated file %s", path);
     std::vector<double> alpha(P * d), r(P), w(P);
     std::vector<int32_t> jh(static_cast<size_t>(n_ids));
     std::vector<uint8_t> del(static_cast<size_t>(n_ids));
@@ -702,15 +779,19 @@ int fspann_index_load(fspann_ctx* c, const char* path) {
     if ((rc = fspann_set_id_meta(c, n_ids, dec ? nullptr : jh.data(), del.data()))) return rc;
     for (int td = 0; td < c->TD; td++) {
         int64_t np = 0, ni = 0;
-        if (!rd(f, &np, 1) || !rd(f, &ni, 1) || np < 0 || ni < 0 || ni > n_ids) return fail(FSPANN_E_ARG, "truncated table %d in %s", td, path);
+        if (!rd(f, &np, 1) || !rd(f, &ni, 1) || np < 0 || ni < 0 || ni > n_ids)
+            return fail(FSPANN_E_ARG, "bad table header %d in %s", td, path);
+        if (np * (16 + 8 * static_cast<long long>(c->W)) + (np + 1) * 8 + ni * 4 > left()) return fail(FSPANN_E_ARG, "truncated table %d in %s", td, path);
         std::vector<int64_t> mn(np), mx(np), off(np + 1);
         std::vector<uint64_t> rep(static_cast<size_t>(np) * c->W);
         std::vector<int32_t> ids(ni);
         if (!rd(f, mn.data(), np) || !rd(f, mx.data(), np) || !rd(f, rep.data(), rep.size()) || !rd(f, off.data(), np + 1) || !rd(f, ids.data(), ni))
             return fail(FSPANN_E_ARG, "truncated table %d in %s", td, path);
+        if (off[0] != 0 || off[np] != ni) return fail(FSPANN_E_ARG, "bad id offsets in table %d of %s", td, path);
         if ((rc = fspann_set_index(c, td, np, mn.data(), mx.data(), rep.data(), off.data(), ids.data()))) return rc;
     }
     return fspann_finalize(c);
+    });
 }
 
 int fspann_index_dims(fspann_ctx* c, int td, int64_t* n_parts, int64_t* n_ids) {
@@ -759,6 +840,7 @@ int fspann_encode(fspann_ctx* c, int64_t nq, const void* q, int dtype, uint64_t*
     const size_t qb = static_cast<size_t>(nq) * c->cfg.dim * esz;
     const size_t cb = static_cast<size_t>(nq) * c->TD * c->W * 8;
     const size_t hb = hashes ? static_cast<size_t>(nq) * c->P_total * 4 : 0;
+    return guarded([&]() -> int {
     int rc;
     if ((rc = ensure(c, c->ws_io[0], qb))) return rc;
     if ((rc = ensure(c, c->ws_io[1], cb))) return rc;
@@ -776,6 +858,7 @@ int fspann_encode(fspann_ctx* c, int64_t nq, const void* q, int dtype, uint64_t*
     for (int64_t i = 0; i < nq; i++)
         if (bad[i]) return fail(FSPANN_E_ARG, "Vector contains NaN/Inf (query %lld)", (long long)i);  // Coding.java:360
     return FSPANN_OK;
+    });
 }
 
 // ---- route --------------------------------------------------------------------------
@@ -817,15 +900,15 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     p.g_scratch = ar_g ? static_cast<unsigned char*>(c->ws_route.p) + ((so_g + 255) & ~size_t(255)) : nullptr;
     p.g_stride = static_cast<int64_t>(pl.arena_bytes);
     p.dbg = c->dbg_route;
-    { const char* e = getenv("FSPANN_ROUTE_DBG_SKIP"); p.dbg_skip = e ? atoi(e) : 0; }
+    p.unmodelled = c->d_unmodelled;
     p.decimal_ids = c->decimal_ids ? 1 : 0;
     p.out_cap = cap; p.out_ids = ids_dev; p.out_score = score_dev; p.out_count = count_dev; p.out_kept = kept_dev; p.out_raw = raw_seen_dev;
     bool fused = false;
     if (pl.lazy) {
         if ((rc = ensure(c, c->ws_ovf, static_cast<size_t>(nq) * 4 + 256))) return rc;
-        if (c->ovf_ptr_seen != c->ws_ovf.p) {    // fresh buffer: both overflow counters start at zero
+        if (c->ovf_gen_seen != c->ws_ovf.gen) {    // fresh allocation: both overflow counters start at zero
             FSP_HIP(hipMemsetAsync(c->ws_ovf.p, 0, 256, c->stream));
-            c->ovf_ptr_seen = c->ws_ovf.p;
+            c->ovf_gen_seen = c->ws_ovf.gen;
         }
         c->ovf_flip ^= 1;
         p.inv = c->d_inv; p.ids_bk = c->d_ids_bk; p.n_ids = c->n_ids; p.lazy_cap = pl.lazy_cap; p.lz_ht_size = pl.lz_ht_size;
@@ -834,8 +917,7 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
         p.ovf_next = static_cast<int32_t*>(c->ws_ovf.p) + 16 * (c->ovf_flip ^ 1);      // ... the next call's is zeroed meanwhile
         p.ovf_list = static_cast<int32_t*>(c->ws_ovf.p) + 64;
         // the probe runs inside the bounded select when its scratch fits the arrays it borrows there
-        const char* fe = getenv("FSPANN_ROUTE_FUSED_PROBE");
-        fused = !(fe && fe[0] == '0') && (kLzThreads / 16) * (2 * pl.P - 1) * 12 <= 4096 && c->TD <= 512;
+        fused = c->knob_fused_probe && (kLzThreads / 16) * (2 * pl.P - 1) * 12 <= 4096 && c->TD <= 512;
         p.probe_G = fused ? 16 : 0;
     }
     // kernel 1: search + probe order, one lane group per (query, table)
@@ -912,6 +994,11 @@ int fspann_route(fspann_ctx* c, int64_t nq, const uint64_t* codes, int probe_ove
     if (kept) FSP_HIP(hipMemcpyAsync(kept, cnt + nq, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
     if (raw_seen) FSP_HIP(hipMemcpyAsync(raw_seen, cnt + 2 * nq, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
     FSP_HIP(hipStreamSynchronize(c->stream));
+    // all outputs are in place; a query whose HashMap would have treeified a bin carries count = -1 and fails the call loudly
+    for (int64_t i = 0; i < nq; i++)
+        if (count[i] < 0)
+            return fail(FSPANN_E_STATE, "query %lld: a HashMap bin of bestScore would be treeified (>= 9 candidate ids in one bin): "
+                        "the JVM's iteration order is not modelled, its count is -1", (long long)i);
     return FSPANN_OK;
 }
 
@@ -1111,6 +1198,17 @@ int fspann_set_route_mode(fspann_ctx* c, int mode) {
     c->route_mode = mode;
     return FSPANN_OK;
 }
+// Queries flagged "unmodelled" (a java.util.HashMap bin would have been treeified; their count is -1) by Route calls of
+// this context since the last reset.  Synchronises the stream.
+int fspann_unmodelled_queries(fspann_ctx* c, int64_t* total, int reset) {
+    CHECK_CTX(c);
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    int32_t v = 0;
+    FSP_HIP(hipMemcpy(&v, c->d_unmodelled, 4, hipMemcpyDeviceToHost));
+    if (total) *total = v;
+    if (reset && v) FSP_HIP(hipMemset(c->d_unmodelled, 0, 4));
+    return FSPANN_OK;
+}
 // Which select the last fspann_route[_dev] ran: *lazy = 1 for the bounded select; *overflowed = queries it handed back
 // to the full select (synchronises the stream).
 int fspann_last_route_info(fspann_ctx* c, int* lazy, int* overflowed) {
@@ -1179,12 +1277,14 @@ int64_t fspann_last_encode_rechecked(fspann_ctx* c) {
     return static_cast<int64_t>(n);
 }
 
-// debug: per-block phase stamps of the route kernel (dev pointer to [grid][8] int64, or NULL)
+#ifdef FSPANN_DEBUG_STAMPS
+// debug builds only (tools/route_stamps.py): per-block phase stamps of the route kernels (dev pointer to [grid][16] int64)
 int fspann_debug_route_stamps(fspann_ctx* c, void* dev_ptr) {
     if (!c) return FSPANN_E_NULL;
     c->dbg_route = static_cast<long long*>(dev_ptr);
     return FSPANN_OK;
 }
+#endif
 
 // ---- device memory helpers -----------------------------------------------------------------
 int fspann_dev_alloc(fspann_ctx* c, size_t bytes, void** out) {
@@ -1229,11 +1329,20 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
     if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
     const int d = c->cfg.dim, TD = c->TD, W = c->W, S = c->cfg.block_size;
     const size_t esz = dtype == FSPANN_F64 ? 8 : 4;
+    c->frozen = false;
+    return guarded([&]() -> int {
     std::vector<int32_t> ord(static_cast<size_t>(n));
     if (order) {
+        // order[] is a permutation of the n handles whose rows `vectors` holds: a handle >= n has no row (and no code),
+        // a repeated handle would put an id twice into every table
         std::copy(order, order + n, ord.begin());
-        for (int64_t i = 0; i < n; i++)
-            if (ord[i] < 0 || ord[i] >= c->n_ids) return fail(FSPANN_E_ARG, "order[%lld] out of range", (long long)i);
+        std::vector<uint64_t> seen(static_cast<size_t>((n + 63) / 64), 0ull);
+        for (int64_t i = 0; i < n; i++) {
+            const int32_t h = ord[i];
+            if (h < 0 || h >= n) return fail(FSPANN_E_ARG, "order[%lld] = %d is not a handle in [0,%lld)", (long long)i, h, (long long)n);
+            if ((seen[static_cast<size_t>(h) >> 6] >> (h & 63)) & 1ull) return fail(FSPANN_E_ARG, "order[] holds handle %d twice", h);
+            seen[static_cast<size_t>(h) >> 6] |= 1ull << (h & 63);
+        }
     } else {  // first MIN_SAMPLE_SIZE-1 inserts are parked and flushed at finalize
         const int64_t ms = 1000;
         int64_t k = 0;
@@ -1273,11 +1382,44 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
         h ^= (h >> 16);
         bucket[i] = h & static_cast<uint32_t>(capf - 1);
     }
+    // The closed form "iteration order = (bucket at the final capacity, insertion order)" holds only while no bin of
+    // HashMap<String,BitSet>(staged.size()) (PIS:413, idx/GreedyPartitioner.java:45-48) is treeified: a put that finds 8
+    // nodes in its bin (table >= 64) turns the bin into a red-black tree whose iteration order is not insertion order.
+    // Replay the bin occupancy put by put, capacity stage by capacity stage, and refuse loudly instead of cutting
+    // partitions in an order the JVM would not produce.
+    {
+        int cap = table_size_for(static_cast<int>(std::min<int64_t>(n, 1 << 30)));
+        int64_t thr = static_cast<int64_t>(static_cast<float>(cap) * 0.75f);
+        std::vector<uint8_t> occ(static_cast<size_t>(cap), 0);
+        for (int64_t i = 0; i < n; i++) {
+            uint32_t h = static_cast<uint32_t>(c->h_java_hash[ord[i]]);
+            h ^= (h >> 16);
+            uint8_t& o = occ[h & static_cast<uint32_t>(cap - 1)];
+            if (o >= 8 && cap >= 64)
+                return fail(FSPANN_E_STATE, "HashMap bin treeified while staging id handle %d (9 ids in one bin at table length %d): "
+                            "the JVM's iteration order is not modelled, import the partitions with fspann_set_index instead", ord[i], cap);
+            if (o < 255) o++;
+            if (i + 1 > thr && cap < (1 << 30)) {      // ++size > threshold -> resize(): every bin splits in two
+                const int oldCap = cap;
+                cap <<= 1;
+                thr = (oldCap >= 16) ? (thr << 1) : static_cast<int64_t>(static_cast<float>(cap) * 0.75f);
+                occ.assign(static_cast<size_t>(cap), 0);
+                for (int64_t j = 0; j <= i; j++) {
+                    uint32_t hj = static_cast<uint32_t>(c->h_java_hash[ord[j]]);
+                    hj ^= (hj >> 16);
+                    uint8_t& oj = occ[hj & static_cast<uint32_t>(cap - 1)];
+                    if (oj < 255) oj++;
+                }
+            }
+        }
+    }
     struct Ent { int64_t key; uint32_t bucket; int32_t pos; };
     // one host thread per table (the cut is independent per (t,d)); the GPU radix-sort version is a "next" item
     const unsigned hw = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
     std::atomic<int> next_td{0};
+    std::atomic<bool> worker_oom{false};
     auto worker = [&]() {
+     try {
       std::vector<Ent> ents(static_cast<size_t>(n));
       for (int td = next_td.fetch_add(1); td < TD; td = next_td.fetch_add(1)) {
         for (int64_t i = 0; i < n; i++) {
@@ -1309,6 +1451,7 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
         of[np] = n;
         c->h_table_set[td] = 1;
       }
+     } catch (...) { worker_oom = true; }
     };
     {
         std::vector<std::thread> pool;
@@ -1317,8 +1460,10 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
         worker();
         for (auto& th : pool) th.join();
     }
+    if (worker_oom) return fail(FSPANN_E_NOMEM, "out of host memory while cutting partitions");
     c->dev_index_dirty = true;
     return fspann_finalize(c);
+    });
 }
 
 }  // extern "C"

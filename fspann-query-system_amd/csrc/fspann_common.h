@@ -61,6 +61,7 @@ struct RouteTable {
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    unsigned gen = 0;   // bumped by every (re)allocation: "same address" does not mean "same contents"
 };
 
 }  // namespace fspann
@@ -77,7 +78,13 @@ struct fspann_ctx {
     int lds_limit = 160 * 1024;
     bool frozen = false;
     bool have_g = false;
-    long long* dbg_route = nullptr;  // debug stamps (fspann_debug_route_stamps)
+    long long* dbg_route = nullptr;  // per-block phase stamps; only reachable in FSPANN_DEBUG_STAMPS builds (tools/)
+    // tuning / test knobs, read from the environment ONCE at fspann_ctx_create (never per call)
+    int knob_ht_x4 = 0;              // FSPANN_ROUTE_HT_X4=1: hash load factor <= 0.5 instead of <= 0.8
+    int knob_threads = 512;          // FSPANN_ROUTE_THREADS=1024
+    int knob_lazy_cap = 0;           // FSPANN_ROUTE_LAZY_CAP: entries one query may hold in the bounded select (tests)
+    int knob_fused_probe = 1;        // FSPANN_ROUTE_FUSED_PROBE=0: separate probe kernel in front of the bounded select
+    int knob_refine_dc = 0;          // FSPANN_REFINE_DC: dims per LDS tile of the refinement scan (tools/refine_bench.py)
 
     // GFunctions: alphaT[dim][P_total] fp64 (transposed for coalescing), r/omega[P_total]
     double* d_alphaT = nullptr;
@@ -116,8 +123,9 @@ struct fspann_ctx {
     fspann::DevBuf ws_search;        // codes / F_q ids / counts of fspann_search_store_dev
     unsigned attr_mask = 0;          // kernels whose dynamic-LDS ceiling has been raised on this context's device
     int ovf_flip = 0;                // which of the two overflow counters the last bounded select used
-    void* ovf_ptr_seen = nullptr;    // ws_ovf.p whose counters have been zeroed
+    unsigned ovf_gen_seen = 0;       // ws_ovf.gen whose counters have been zeroed (0 = never)
     int last_route_lazy = 0;         // 1 if the last fspann_route[_dev] ran the bounded select
+    int32_t* d_unmodelled = nullptr; // device counter: queries flagged "HashMap bin treeified" (out_count = -1) since the last reset
     int64_t total_parts = 0, total_ids = 0;
 
     // id metadata
@@ -152,6 +160,7 @@ inline int ensure(fspann_ctx* c, DevBuf& b, size_t bytes) {
     size_t want = bytes + bytes / 4 + 256;
     FSP_HIP(hipMalloc(&b.p, want));
     b.bytes = want;
+    b.gen++;
     return FSPANN_OK;
 }
 

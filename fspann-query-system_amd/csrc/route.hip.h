@@ -78,8 +78,8 @@ struct RouteParams {
     int32_t* ovf_list;
     const int32_t* qcount;         // ... and consumed by route_select_kernel (qlist mode: only these queries)
     const int32_t* qlist;
-    int dbg_skip;                  // debug: bit0 = skip the hash build (timing experiments only)
-    long long* dbg;                // optional [grid][16] wall_clock64 stamps of each block's first query
+    int32_t* unmodelled;           // context-wide count of queries whose HashMap would have treeified a bin (out_count = -1)
+    long long* dbg;                // FSPANN_DEBUG_STAMPS builds: [grid][16] wall_clock64 stamps of each block's first query (else unused)
 };
 
 __device__ __forceinline__ int ham_words(const uint64_t* a, const uint64_t* b, int W) {
@@ -360,13 +360,17 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
     int32_t* nprobe = reinterpret_cast<int32_t*>(sm + so);       so += static_cast<size_t>(TD) * 4;
     int32_t* dupcnt = reinterpret_cast<int32_t*>(sm + so);       // [TD]
 
-    __shared__ int s_n, s_raw, s_fill, s_cut, s_star, s_need, s_b1, s_lvl1, s_ndup;
+    __shared__ int s_n, s_raw, s_fill, s_cut, s_star, s_need, s_b1, s_lvl1, s_ndup, s_tree, s_suspect;
 
     const uint32_t ht_mask = static_cast<uint32_t>(prm.ht_size - 1);
 
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
 
+#ifdef FSPANN_DEBUG_STAMPS
 #define FSP_STAMP(i) do { if (prm.dbg && tid == 0 && qq == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define FSP_STAMP(i) do { } while (0)
+#endif
 #define FSP_TS(j) ((prm.S_shift >= 0) ? ((j) >> prm.S_shift) : ((j) / S))
 
     // hash entries are (tag(id) << seq_bits) | seq: a failed CAS can tell "other id" from the returned word alone;
@@ -381,11 +385,14 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
     auto find_slot = [&](int32_t id) -> uint32_t {
         uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> prm.ht_shift;
         const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> prm.ht_shift) | 1u;
-        while (true) {
+        // the id was inserted by B1, so its slot is met on its probe sequence; the trip bound (an odd step visits every
+        // slot of the power-of-two table once) only keeps a host-side slip from turning into waves that never finish
+        for (int tries = 0; tries < prm.ht_size; tries++) {
             const uint32_t cur = ht[slot];
             if (cur != kHtEmpty && (cur >> prm.seq_bits) == id_tag(id) && tup[cur & seq_mask] == id) return slot;
             slot = (slot + stp) & ht_mask;
         }
+        return slot;
     };
 
     const int64_t nq_eff = prm.qlist ? static_cast<int64_t>(*prm.qcount) : prm.nq;
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
             for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;
             for (int i = tid; i < TP; i += nthreads) { stepcnt[i] = 0; probe[i] = probe_in[qi * TP + i]; }
             for (int i = tid; i < TD; i += nthreads) { dupcnt[i] = 0; nprobe[i] = nprobe_in[qi * TD + i]; }
-            if (tid == 0) { s_n = 0; s_raw = 0; s_fill = 0; s_cut = 0x7FFFFFFF; s_ndup = 0; s_lvl1 = 0; }
+            if (tid == 0) { s_n = 0; s_raw = 0; s_fill = 0; s_cut = 0x7FFFFFFF; s_ndup = 0; s_lvl1 = 0; s_tree = 0; s_suspect = 0; }
         }
         __syncthreads();
         FSP_STAMP(1);
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
         // tuples (j = tid, tid + nthreads, ...) one probe step per loop trip, so a lane with a long probe
         // sequence does not stall the other 63: the wave finishes after max-over-lanes of the SUM of probe
         // lengths instead of the sum of per-tuple maxima.
-        if (!(prm.dbg_skip & 1)) {
+        {
             int j = tid;
             int32_t id = -1;
             uint32_t slot = 0, stp = 1, mytag = 0;
@@ -687,7 +694,9 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
         __syncthreads();
         FSP_STAMP(4);
         const int nsel = s_fill;
+#ifdef FSPANN_DEBUG_STAMPS
         if (tid == 0 && prm.dbg && qq == blockIdx.x) prm.dbg[blockIdx.x * 16 + 15] = nsel;
+#endif
         const int nout = min(nsel, prm.limit);
         if (nsel <= kRankSortMax - 128 && prm.sort_cap >= kRankSortMax) {
             // all-pairs rank: keys are unique (seq is), so rank = #smaller keys; no barriers.
@@ -738,8 +747,104 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
             }
         }
         FSP_STAMP(5);
+        // ---- T: would java.util.HashMap have treeified a bin?  The order key above (bucket, first insertion) is the
+        // iteration order of `bestScore` (PIS:619,690-693) only while every bin is a plain chain.  putVal() turns a bin into a
+        // red-black tree when a put finds 8 nodes in it (table >= 64, guaranteed by cap0 >= 64): from then on the bin's
+        // iteration order is not insertion order and is NOT modelled here.  Detect it exactly and flag the query
+        // (out_count = -1, prm.unmodelled++) instead of returning a list the JVM would not produce.
+        //   stage k of the map: table length cap0 << k while size <= thr_k (thr_0 = 0.75 cap0, doubling); a bin of stage k
+        //   treeifies iff >= 9 of the first thr_k + 1 distinct ids (in insertion order) share it.
+        // ht (dead since B3) is reused: first as direct-indexed counters over the cap0 buckets folded to ht_size (a cheap
+        // necessary condition: bins only split when the table grows), then — only for a suspect query, or when the map
+        // resized — as an open-addressed (bucket -> count) table per stage.
+        {
+            const int thr0 = static_cast<int>(static_cast<float>(prm.cap0) * 0.75f);
+            const bool single = (n <= thr0);                       // the map never resized: one stage, no ranks needed
+            auto spread_of = [&](int32_t id) -> uint32_t {
+                uint32_t h = prm.decimal_ids ? decimal_string_hash_dev(static_cast<uint32_t>(id)) : static_cast<uint32_t>(prm.java_hash[id]);
+                return h ^ (h >> 16);
+            };
+            __syncthreads();       // ht, tscore: every wave is past its last use
+            {
+                uint4* h4 = reinterpret_cast<uint4*>(ht);
+                for (int i = tid; i < prm.ht_size / 4; i += nthreads) h4[i] = make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads();
+            for (int j = tid; j < prm.max_tuples; j += nthreads) {
+                if (!(tscore[j] & kFirstFlag)) continue;
+                const uint32_t b0 = spread_of(tup[j]) & static_cast<uint32_t>(prm.cap0 - 1);
+                if (atomicAdd(&ht[b0 & ht_mask], 1u) >= 8u) s_suspect = 1;
+            }
+            __syncthreads();
+            const bool exact0 = single && prm.ht_size >= prm.cap0;   // no folding, one stage: the counters ARE the bins
+            if (s_suspect && exact0) { if (tid == 0) s_tree = 1; }
+            else if (s_suspect) {
+                // exact pass.  Insertion rank of a first occurrence = distinct ids of earlier probe steps + earlier first
+                // occurrences inside its own step (tuples of a step are laid out in insertion order).
+                if (wave == 0) {     // exclusive prefix of stepcnt over the steps that ran
+                    int carry = 0;
+                    for (int g0 = 0; g0 < TP; g0 += 64) {
+                        const int g = g0 + lane;
+                        const int v = (g < TP && g <= cut) ? stepcnt[g] : 0;
+                        int incl = v;
+                        for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+                        if (g < TP) stepcnt[g] = carry + incl - v;
+                        carry += __shfl(incl, 63);
+                    }
+                }
+                const int SPt = (S + 63) >> 6, nwv = nthreads >> 6;
+                int capk = prm.cap0;
+                long long thrk = thr0;
+                for (int stage = 0; stage < 24; stage++) {
+                    const long long endk = (thrk < static_cast<long long>(n) - 1) ? thrk : static_cast<long long>(n) - 1;   // last rank of this stage
+                    __syncthreads();
+                    {
+                        uint4* h4 = reinterpret_cast<uint4*>(ht);
+                        const uint4 e4 = make_uint4(kHtEmpty, kHtEmpty, kHtEmpty, kHtEmpty);
+                        for (int i = tid; i < prm.ht_size / 4; i += nthreads) h4[i] = e4;
+                    }
+                    __syncthreads();
+                    for (int ts = wave; ts < TP; ts += nwv) {          // wave-uniform: the ballots need every lane
+                        if (ts > cut) break;
+                        int carry = stepcnt[ts];
+                        for (int pc = 0; pc < SPt; pc++) {
+                            const int pos = pc * 64 + lane;
+                            const int j = ts * S + pos;
+                            const bool f = (pos < S) && (tscore[j] & kFirstFlag);
+                            const unsigned long long bm = __ballot(f);
+                            const int rank = carry + __popcll(bm & ((1ull << lane) - 1ull));
+                            carry += __popcll(bm);
+                            if (!f || rank > endk) continue;
+                            const uint32_t b = spread_of(tup[j]) & static_cast<uint32_t>(capk - 1);     // < 2^20
+                            uint32_t slot = (b * 2654435761u) >> prm.ht_shift;
+                            const uint32_t stp = ((b * 0x85EBCA6Bu) >> prm.ht_shift) | 1u;
+                            for (int tries = 0; tries < prm.ht_size; tries++) {    // <= n <= 0.8 ht_size keys: an empty slot exists
+                                uint32_t cur = ht[slot];
+                                if (cur == kHtEmpty) {
+                                    cur = atomicCAS(&ht[slot], kHtEmpty, (b << 11) | 1u);
+                                    if (cur == kHtEmpty) break;                    // created with count 1
+                                }
+                                if ((cur >> 11) == b) {                            // the key of a slot never changes
+                                    if ((cur & 2047u) >= 9u || (atomicAdd(&ht[slot], 1u) & 2047u) + 1u >= 9u) s_tree = 1;
+                                    break;
+                                }
+                                slot = (slot + stp) & ht_mask;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (s_tree || thrk >= static_cast<long long>(n) - 1) break;     // block-uniform
+                    capk <<= 1;
+                    thrk <<= 1;
+                    if (capk > (1 << kBucketBits)) break;                          // beyond the bucket field (host rejects such caps)
+                }
+            }
+            __syncthreads();
+        }
+        const bool treeified = (s_tree != 0);
         if (tid == 0) {
-            prm.out_count[qi] = nout;
+            if (treeified && prm.unmodelled) atomicAdd(prm.unmodelled, 1);
+            prm.out_count[qi] = treeified ? -1 : nout;
             if (prm.out_kept) prm.out_kept[qi] = n;
             if (prm.out_raw) prm.out_raw[qi] = n + s_raw;
         }

@@ -149,7 +149,11 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
         return false;
     };
 
+#ifdef FSPANN_DEBUG_STAMPS
 #define LZ_STAMP(i) do { if (prm.dbg && tid == 0 && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define LZ_STAMP(i) do { } while (0)
+#endif
 // Every live tuple of the sorted probes [RA, RB): BODY sees `id` (>= 0 when live and not deleted, else -1), its bucket
 // field `bf` and the partition's distance `sc`;
 // kLzStageU partitions are in flight per wave (one coalesced 256-byte id row each).  Trip counts are wave-uniform.
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
         bool overflow = false;
         int r0 = 0, u = 0;
         int dbg_outer = 0, dbg_inner = 0, dbg_reload = 0, dbg_nitb = 0;
+        (void)dbg_outer; (void)dbg_inner; (void)dbg_reload; (void)dbg_nitb;   // read only in FSPANN_DEBUG_STAMPS builds
         bool force_full = false;
         // ---- 2. walk the distance levels ---------------------------------------------------------------------------
         while (r0 < R && u < prm.limit) {
@@ -467,6 +472,9 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             for (int i = tid; i < nsel; i += nthreads) {
                 const int lt = lrank[i];
                 if (rk[lt] != 1) {   // shares (score, bucket) with another entry: settled below by insertion sequence
+                    // nine ids in one HashMap bin: the JVM treeifies it and its iteration order is no longer insertion
+                    // order.  The full select detects that exactly (route.hip.h, phase T): hand the query over.
+                    if (rk[lt] >= 9) s_bad = 1;
                     const int c = atomicAdd(&s_ncoll, 1);
                     if (c < kLzCollMax) { c_elem[c] = i; c_lt[c] = lt; c_id[c] = static_cast<int32_t>(ht[ulist[i]] >> 32); c_seq[c] = 0x7FFFFFFF; }
                 }
@@ -474,8 +482,10 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             __syncthreads();
             LZ_STAMP(5);
             const int ncoll = s_ncoll;
+#ifdef FSPANN_DEBUG_STAMPS
             if (tid == 0 && prm.dbg && qi == blockIdx.x) { prm.dbg[blockIdx.x * 16 + 13] = ncoll; prm.dbg[blockIdx.x * 16 + 15] = nsel; prm.dbg[blockIdx.x * 16 + 14] = dbg_outer | (dbg_inner << 8) | (dbg_reload << 16) | (static_cast<long long>(dbg_nitb) << 24); }
-            if (ncoll > kLzCollMax) {
+#endif
+            if (ncoll > kLzCollMax || s_bad) {
                 overflow = true;
             } else {
                 if (ncoll > 0) {

@@ -194,10 +194,18 @@ class FspannContext:
         N.check(self.L.fspann_last_route_info(self._h, C.byref(lazy), C.byref(ovf)))
         return dict(lazy=bool(lazy.value), overflowed=int(ovf.value))
 
+    def unmodelled_queries(self, reset=True) -> int:
+        """Queries flagged 'HashMap bin treeified' (count = -1) by Route calls since the last reset."""
+        v = C.c_int64(0)
+        N.check(self.L.fspann_unmodelled_queries(self._h, C.byref(v), 1 if reset else 0))
+        return int(v.value)
+
     def route_max_candidates(self, probe_override=-1):
         return int(self.L.fspann_route_max_candidates(self._h, probe_override))
 
-    def route(self, codes, probe_override=-1, limit=N.INT32_MAX, cap=None, counters=True):
+    def route(self, codes, probe_override=-1, limit=N.INT32_MAX, cap=None, counters=True, allow_unmodelled=False):
+        """allow_unmodelled: return the per-query flags (count = -1: a HashMap bin would be treeified, the JVM's order
+        is not modelled) instead of raising FspannStateError for the whole batch."""
         if codes is None:
             raise N.FspannStateError("MSANNP violation: QueryToken missing BitSet codes")
         codes = _c(codes, np.uint64).reshape(-1, self.TD, self.W)
@@ -209,8 +217,10 @@ class FspannContext:
         count = np.zeros(nq, np.int32)
         kept = np.zeros(nq, np.int32)
         raw = np.zeros(nq, np.int32)
-        N.check(self.L.fspann_route(self._h, nq, _p(codes), probe_override, min(limit, N.INT32_MAX), cap, _p(ids),
-                                    _p(score), _p(count), _p(kept) if counters else None, _p(raw) if counters else None))
+        rc = self.L.fspann_route(self._h, nq, _p(codes), probe_override, min(limit, N.INT32_MAX), cap, _p(ids),
+                                 _p(score), _p(count), _p(kept) if counters else None, _p(raw) if counters else None)
+        if not (allow_unmodelled and rc == N.E_STATE and (count < 0).any()):   # outputs are complete in that case
+            N.check(rc)
         if not counters:   # lastCandKept / rawSeen not requested: the bounded select may run
             return dict(ids=ids, score=score, count=count)
         return dict(ids=ids, score=score, count=count, kept=kept, raw_seen=raw)

@@ -153,6 +153,17 @@ int fspann_route(fspann_ctx* ctx, int64_t nq, const uint64_t* codes, int probe_o
 int fspann_route_dev(fspann_ctx* ctx, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit,
                      int64_t cap, int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev,
                      int32_t* raw_seen_dev);
+/* JDK HashMap order and its limit.  The list order above is the iteration order of HashMap<String,Long> bestScore
+ * (PIS:619,690-693) stable-sorted by score; the library derives it in closed form (bin index at the map's final table
+ * length, then first insertion) — exact while every bin is a plain chain.  A put that finds 8 nodes in its bin makes the
+ * JVM treeify that bin, after which its iteration order is NOT modelled.  That case is detected exactly (per capacity
+ * stage of the map) and fails loudly instead of returning a non-Java order: the query's count is set to -1 (Refine then
+ * scores nothing for it), fspann_route returns FSPANN_E_STATE after writing all outputs, and for the asynchronous _dev
+ * entry points fspann_unmodelled_queries reports how many queries were flagged since the last reset (synchronises).
+ * fspann_build_index applies the same rule to HashMap<String,BitSet>(staged.size()) (PIS:413) and returns FSPANN_E_STATE.
+ * The bounded select hands a query to the full select when >= 9 of the entries it holds share (score, bin); a bin that
+ * reaches 9 ids only through candidates the bounded select never loads is not seen by it ("treeified bins"). */
+int fspann_unmodelled_queries(fspann_ctx* ctx, int64_t* total, int reset);
 /* Worst-case entries per query for (probes): min(T*D*probes*block_size, HARD_CAP + block_size - 1). */
 int64_t fspann_route_max_candidates(fspann_ctx* ctx, int probe_override);
 int fspann_effective_probes(fspann_ctx* ctx, int probe_override); /* PIS:880-888 */

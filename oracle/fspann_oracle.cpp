@@ -493,7 +493,7 @@ int collectPartitionOrdered(const Ctx& c, const Partition& p, const uint64_t* qB
 // Shared traversal of PIS.lookupCandidateIds (:459-582) and
 // PIS.lookupCandidatesWithScores (:592-715).  qCodes = [TD][W].
 // Returns entries stable-sorted by score in HashMap iteration order.
-void routeTraverse(Ctx& c, const uint64_t* qCodes, int probes, std::vector<Cand>& out, int& rawSeen) {
+void routeTraverse(Ctx& c, const uint64_t* qCodes, int probes, std::vector<Cand>& out, int& rawSeen, bool* treeified = nullptr) {
     const int W = c.W();
     const int HARD_CAP = std::max(c.maxGlobalCandidates, c.refinementLimit);  // PIS:612-615
     JHashMap best(std::min(HARD_CAP, 1 << 16));                                // PIS:619
@@ -529,6 +529,7 @@ void routeTraverse(Ctx& c, const uint64_t* qCodes, int probes, std::vector<Cand>
         }
     }
     if (best.unmodelled) c.unmodelled = true;
+    if (treeified) *treeified = best.unmodelled;
     out.clear();
     out.reserve(best.size);
     best.forEach([&](int32_t id, int64_t v) { out.push_back({id, v}); });     // PIS:690-693
@@ -906,6 +907,20 @@ int64_t orc_route(void* p, int64_t nq, const uint64_t* codes, int probeOverride,
         }
     }
     return mx;
+}
+
+// Per query: did the literal HashMap model meet a treeifyBin() on a table >= 64 (iteration order unmodelled)?
+void orc_route_treeified(void* p, int64_t nq, const uint64_t* codes, int probeOverride, uint8_t* flags) {
+    Ctx* c = static_cast<Ctx*>(p);
+    const int W = c->W(), TD = c->TD();
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t i = 0; i < nq; i++) {
+        std::vector<Cand> out;
+        int raw = 0;
+        bool t = false;
+        routeTraverse(*c, codes + (size_t)i * TD * W, effectiveMaxProbes(*c, probeOverride), out, raw, &t);
+        flags[i] = t ? 1 : 0;
+    }
 }
 
 // Full search for a batch.  out_ids/out_dist = [nq][K]; sel = [nq][selCap] (stage A.5 list of last pass).

@@ -292,6 +292,13 @@ class Oracle:
                         C.c_int64(cap), _p(ids), _p(score), _p(count), _p(raw))
         return ids, score, count, raw
 
+    def route_treeified(self, codes, probe_override=-1):
+        """Per query: True where java.util.HashMap would have treeified a bin of bestScore (order unmodelled)."""
+        codes = _c(codes, np.uint64).reshape(-1, self.TD, self.W)
+        flags = np.zeros(codes.shape[0], np.uint8)
+        lib().orc_route_treeified(self._h, C.c_int64(codes.shape[0]), _p(codes), C.c_int(probe_override), _p(flags))
+        return flags.astype(bool)
+
     def search(self, q, K, codes=None, probe_override=-1, refine_override=0, sel_cap=None, threads=0):
         q = _c(q, np.float64).reshape(-1, self.d)
         nq = q.shape[0]

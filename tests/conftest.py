@@ -13,6 +13,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fullsize: GPU parity at BASELINE.json's full sizes (minutes; part of -m gpu)")
 
 
 @pytest.fixture(scope="session")

@@ -193,22 +193,39 @@ def test_bounded_select_bucket_collisions(pkg, oracle):
         assert all(r["lazy"] for r in LAZY_RUNS[before:])
 
 
-def test_bounded_select_degenerate_hash_hands_back(pkg, oracle):
-    """Every survivor in the same few buckets: more collisions than the bounded select settles itself -> the full
-    select redoes those queries.  (The reference HashMap would treeify here, so the oracle has no order to offer:
-    the two product paths are compared with each other.)"""
-    n = 30000
-    sc = make_scene(oracle, n=n, d=16, T=8, D=1, m=12, lam=2, B=256, seed=24)
-    codes = sc["oracle"].encode(sc["rng"].standard_normal((24, 16)))
-    with ctx_for(pkg, sc, java_hash=(np.arange(n) % 5).astype(np.int32)) as ctx:
-        ctx.build_index(sc["X"])
-        full = ctx.route(codes, limit=256)
-        ctx.set_route_mode(2)
-        lazy = ctx.route(codes, limit=256, counters=False)
-        info = ctx.last_route_info()
-    assert info["lazy"] and info["overflowed"] == 24
-    assert np.array_equal(lazy["count"], full["count"])
-    assert np.array_equal(lazy["ids"], full["ids"]) and np.array_equal(lazy["score"], full["score"])
+def test_bounded_select_many_collisions_hands_back(pkg, oracle):
+    """More entries sharing (score, HashMap bin) than the bounded select settles itself (kLzCollMax) -> the full select
+    redoes the query.  The hashCodes are laid out per query so that every bin holds 4 of its candidates: far from the 9
+    that would treeify a bin (tests/test_gpu_treeify.py covers that side), so the oracle's order is the reference's."""
+    n = 20000
+    sc = make_scene(oracle, n=n, d=16, T=1, D=1, m=12, lam=2, B=256, seed=24)
+    o = sc["oracle"]
+    Q = sc["rng"].standard_normal((3, 16))
+    codes = o.encode(Q)
+    base = oracle.decimal_hashes(n).astype(np.int64)
+    for qi in range(3):
+        ids0, _, cnt0, _ = o.route(codes[qi:qi + 1])
+        jh = (base * 65536 + 40000).astype(np.int64)              # everything else: bins far away from the crafted ones
+        cands = ids0[0, :cnt0[0]]
+        jh[cands] = (np.arange(len(cands)) // 4) * 65536          # spread(h) & (cap-1) = h >> 16: bin j // 4
+        jh = (jh & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        o.set_id_meta(n, jh)
+        ids, score, count, raw = o.route(codes[qi:qi + 1])         # same partitions, new HashMap order
+        assert not o.route_treeified(codes[qi:qi + 1]).any()
+        with ctx_for(pkg, sc, java_hash=jh) as ctx:
+            for td in range(o.TD):
+                ctx.set_index(td, **o.get_index(td))
+            ctx.finalize()
+            full = ctx.route(codes[qi:qi + 1], limit=256)
+            ctx.set_route_mode(2)
+            lazy = ctx.route(codes[qi:qi + 1], limit=256, counters=False)
+            info = ctx.last_route_info()
+        assert info["lazy"] and info["overflowed"] == 1
+        c = min(256, count[0])
+        assert full["count"][0] == c and lazy["count"][0] == c
+        assert np.array_equal(full["ids"][0, :c], ids[0, :c]) and np.array_equal(lazy["ids"][0, :c], ids[0, :c])
+        assert np.array_equal(lazy["score"][0, :c], score[0, :c])
+    o.set_id_meta(n)
 
 
 @pytest.mark.parametrize("block_size", [16, 100, 128])
