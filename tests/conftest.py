@@ -26,6 +26,14 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def pkg():
+    # torch ships its own copy of the HIP runtime: when both live in one process, torch's must be initialised first
+    # (a second runtime initialised after libfspann_hip.so has opened the device sees no GPU)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     return graft.load_package()
 
 

@@ -195,10 +195,10 @@ def test_bounded_select_bucket_collisions(pkg, oracle):
 
 def test_bounded_select_many_collisions_hands_back(pkg, oracle):
     """More entries sharing (score, HashMap bin) than the bounded select settles itself (kLzCollMax) -> the full select
-    redoes the query.  The hashCodes are laid out per query so that every bin holds 4 of its candidates: far from the 9
+    redoes the query.  The hashCodes are laid out per query so that every bin holds 3 of its candidates: far from the 9
     that would treeify a bin (tests/test_gpu_treeify.py covers that side), so the oracle's order is the reference's."""
     n = 20000
-    sc = make_scene(oracle, n=n, d=16, T=1, D=1, m=12, lam=2, B=256, seed=24)
+    sc = make_scene(oracle, n=n, d=16, T=1, D=1, m=12, lam=2, B=300, seed=24)
     o = sc["oracle"]
     Q = sc["rng"].standard_normal((3, 16))
     codes = o.encode(Q)
@@ -207,7 +207,7 @@ def test_bounded_select_many_collisions_hands_back(pkg, oracle):
         ids0, _, cnt0, _ = o.route(codes[qi:qi + 1])
         jh = (base * 65536 + 40000).astype(np.int64)              # everything else: bins far away from the crafted ones
         cands = ids0[0, :cnt0[0]]
-        jh[cands] = (np.arange(len(cands)) // 4) * 65536          # spread(h) & (cap-1) = h >> 16: bin j // 4
+        jh[cands] = (np.arange(len(cands)) // 3) * 65536          # spread(h) & (cap-1) = h >> 16: bin j // 3 (the ~320 entries the select holds at limit 300 all collide: > kLzCollMax)
         jh = (jh & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
         o.set_id_meta(n, jh)
         ids, score, count, raw = o.route(codes[qi:qi + 1])         # same partitions, new HashMap order
@@ -216,12 +216,12 @@ def test_bounded_select_many_collisions_hands_back(pkg, oracle):
             for td in range(o.TD):
                 ctx.set_index(td, **o.get_index(td))
             ctx.finalize()
-            full = ctx.route(codes[qi:qi + 1], limit=256)
+            full = ctx.route(codes[qi:qi + 1], limit=300)
             ctx.set_route_mode(2)
-            lazy = ctx.route(codes[qi:qi + 1], limit=256, counters=False)
+            lazy = ctx.route(codes[qi:qi + 1], limit=300, counters=False)
             info = ctx.last_route_info()
         assert info["lazy"] and info["overflowed"] == 1
-        c = min(256, count[0])
+        c = min(300, count[0])
         assert full["count"][0] == c and lazy["count"][0] == c
         assert np.array_equal(full["ids"][0, :c], ids[0, :c]) and np.array_equal(lazy["ids"][0, :c], ids[0, :c])
         assert np.array_equal(lazy["score"][0, :c], score[0, :c])

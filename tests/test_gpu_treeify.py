@@ -62,7 +62,7 @@ def test_route_flags_agree_with_literal_hashmap(pkg, oracle, hard_cap, B):
         n = int(rng.integers(1500, 6000))
         sc = make_scene(oracle, n=n, d=12, T=4, D=2, m=8, lam=2, B=B, hard_cap=hard_cap, seed=40 + seed)
         o = sc["oracle"]
-        V = int(rng.choice([60, 150, 400, 2000]))
+        V = [60, 400, 2000, 10**6, 150, 10**6][seed]       # crowded bins ... well-spread hashCodes
         jh = (rng.integers(0, V, n) * int(rng.choice([1, 64, 4096, 65536 + 17]))).astype(np.int32)
         o.set_id_meta(n, jh)
         o.build_index(sc["X64"])              # partitions of the literal model (their tie order may be unmodelled: imported as data)
