@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — whole-job queries/s of the TokenGen -> Route -> Refine hot path on N MI355X.
+"""bench.py — whole-job queries/s of FSPANN's TokenGen -> Route -> Refine hot path on N MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
-torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from env).
-One "step" = one pass of the hot path over one batch of `--batch` queries PER GPU
-(weak scaling: the index is replicated, query batches shard embarrassingly):
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run, one rank per
+GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env).  One "step" = one pass of the hot path over one batch of
+`--batch` queries PER GPU (weak scaling: the index is replicated, query batches shard embarrassingly):
 
-    encode (exact fp64 Coding.H/C)  ->  route (probe + dedupe + Java-order select-B)
-    -> candidate staging (device gather from a plaintext store: stand-in for the host's
-       load + AES-GCM decrypt, which stay on the host in production)
-    -> refine (sequential-fp64 L2 scan + stable top-k)  [-> RCCL all-gather of top-k, N > 1]
+    encode  (Coding.H/C, sequential fp64)                                   idx/Coding.java:250-301
+ -> route   (probe + HashMap-ordered candidate list, first B = stage A.5)   PIS:592-715, QSI:169-214
+ -> refine  (sequential-fp64 L2 scan over the candidate rows + stable top-k) QSI:238-316
+ [-> one RCCL all-gather of the per-rank top-k, N > 1]
 
-All inputs (queries, frozen index, plaintext store) are resident in HBM before the timed
-region.  Rank 0 prints ONE JSON line.  Extra objects: `roofline` (refine scan, live HIP-event
-timing on the context's stream), `cpu_baseline` (the C++ oracle on this box's host cores,
-bounded sample), `stages_ms`, `recall_at_10`.
+`value` is the KERNEL PATH of SURVEY §8(d): the [Q x B x d] blocks of decrypted candidate rows — what the host's
+loadPointIfActive + AES-GCM decrypt loop hands over in production — are already resident in HBM when the timed region
+starts (`--candidates dense`; packed once, before the timed region, for each of the `--query-batches` distinct batches,
+so consecutive steps read DIFFERENT blocks: 32 x 134 MB = 4.3 GB cycled, far beyond the 256 MiB Infinity Cache).
+Beside it (extra objects, never `value`): the trusted-HBM variant where Refine reads plaintext rows of a resident store
+by id (`variants.store`), the gather-inclusive variant, two contexts alternating (`pipelined`), the refine scan on an
+8 M-row store and at config #4's shape (`roofline.hbm_proof`, `roofline.cfg4_shape`), recall@10 / distance ratio vs
+exact kNN, and the CPU oracle on this box's host cores (`cpu_baseline`).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -30,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 WORKLOADS = {
     # BASELINE.json configs[1]: SIFT-1M-shaped, 16 tables x 32 bits (m=16, lambda=2, divisions=1), B=256, batch=1024
@@ -44,6 +47,60 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def read_fvecs(path, limit=None):
+    """.fvecs: per record int32 dim + dim float32 (little endian), loader/FvecsLoader.java:21-35 (values are then widened
+    float -> double, :29: the data are exactly fp32-representable, which is what the scan's bit-exactness relies on)."""
+    a = np.fromfile(path, dtype=np.int32)
+    if a.size == 0:
+        raise ValueError(f"{path}: empty")
+    d = int(a[0])
+    if d <= 0 or a.size % (d + 1) != 0:
+        raise ValueError(f"{path}: not an fvecs file (dim {d}, {a.size} words)")
+    a = a.reshape(-1, d + 1)
+    if not (a[:, 0] == d).all():
+        raise ValueError(f"{path}: records of different dimension")
+    out = a[:, 1:].view(np.float32)
+    return np.ascontiguousarray(out[:limit] if limit else out)
+
+
+def read_ivecs(path, limit=None):
+    """.ivecs ground truth: per record int32 k + k int32 ids (loader/GroundtruthManager.java:69-146)."""
+    a = np.fromfile(path, dtype=np.int32)
+    k = int(a[0])
+    a = a.reshape(-1, k + 1)
+    return np.ascontiguousarray(a[:limit, 1:] if limit else a[:, 1:])
+
+
+def make_data(kind, n, d, nb, q, seed, rank):
+    """Base vectors (same on every rank) and nb x q queries (per rank).  gaussian: iid N(0,1) (north_star's throughput data;
+    no LSH has signal there).  clustered: 4096 Gaussian blobs (sigma 0.15 around N(0,1) centres), queries from the same
+    mixture — synthetic data on which recall means something.  <path>.fvecs: real vectors, queries from <path> with
+    'base' -> 'query' in the name when present."""
+    rng = np.random.default_rng(seed)
+    qrng = np.random.default_rng(seed + 1000 + rank)
+    if kind == "gaussian":
+        X = rng.standard_normal((n, d), dtype=np.float32)
+        Qs = qrng.standard_normal((nb, q, d), dtype=np.float32)
+        return X, Qs, "synthetic N(0,1) fp32 vectors (SIFT-1M shape)"
+    if kind == "clustered":
+        nc = 4096
+        C = rng.standard_normal((nc, d), dtype=np.float32)
+        X = C[rng.integers(0, nc, n)] + np.float32(0.15) * rng.standard_normal((n, d), dtype=np.float32)
+        Qs = C[qrng.integers(0, nc, nb * q)] + np.float32(0.15) * qrng.standard_normal((nb * q, d), dtype=np.float32)
+        return X, Qs.reshape(nb, q, d), "synthetic clustered fp32 vectors (4096 Gaussian blobs, sigma 0.15)"
+    X = read_fvecs(kind, n)
+    if X.shape[1] != d:
+        raise SystemExit(f"{kind}: dim {X.shape[1]} != workload dim {d}")
+    qpath = kind.replace("base", "query")
+    if qpath != kind and os.path.exists(qpath):
+        Qf = read_fvecs(qpath)
+    else:
+        Qf = X[qrng.integers(0, len(X), nb * q)] + np.float32(0.01) * qrng.standard_normal((nb * q, d), dtype=np.float32)
+    reps = -(-nb * q // len(Qf))
+    Qs = np.tile(Qf, (reps, 1))[: nb * q].reshape(nb, q, d)
+    return X, np.ascontiguousarray(Qs), f"{os.path.basename(kind)} ({len(X)} x {d}), queries tiled to {nb} x {q}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,25 +108,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="sift1m_T16_b32_B256_Q1024", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="queries per GPU per step (default: workload's)")
+    ap.add_argument("--data", default="gaussian", help="gaussian | clustered | path to a .fvecs base file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=512, help="queries timed on the CPU oracle")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra passes (store / gather variants, pipelined, HBM proof)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--query-batches", type=int, default=8,
-                    help="distinct query batches cycled through by the steps (a repeated batch would re-read the same "
-                         "candidate rows out of the 256 MiB Infinity Cache instead of HBM)")
-    ap.add_argument("--merge", default="auto", choices=["auto", "inline", "overlap"],
-                    help="N > 1: the RCCL all-gather of the per-rank top-k follows Refine on the same stream (inline), or runs on "
-                         "a side stream overlapping the next step (overlap; costs two cross-stream events per step). auto: both "
-                         "are tried for a few untimed steps before the warmup and the faster one is used by every rank")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream pass reported under 'pipelined'")
-    ap.add_argument("--route-counters", action="store_true",
-                    help="also produce lastCandKept / rawSeen per query (forces the full select)")
-    ap.add_argument("--candidates", default="store", choices=["store", "dense"],
-                    help="store: refine reads candidate rows from the resident store by id; dense: a gather kernel packs "
-                         "them into [Q][B][d] first (explicit stand-in for the host's load + decrypt)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="contexts (HIP streams) per GPU that alternate steps; 2 overlaps the latency-bound Route of step i+1 "
-                         "with the bandwidth-bound gather/refine of step i (per-stage times then include the overlap)")
+    ap.add_argument("--query-batches", type=int, default=32,
+                    help="distinct query batches (and dense candidate blocks) cycled through by the steps: 32 x 134 MB = 4.3 GB, "
+                         "so a step never finds its rows in the 256 MiB Infinity Cache")
+    ap.add_argument("--candidates", default="dense", choices=["dense", "store", "gather"],
+                    help="dense (value): Refine scans the [Q][B][d] block of decrypted rows resident in HBM, packed before the timed "
+                         "region; store: Refine reads rows of a resident plaintext store by id (trusted-HBM variant, one library "
+                         "call per step); gather: a kernel packs the block inside the step (device stand-in for load + decrypt)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch queries per GPU per step; strong: ONE batch of the workload's size cut into contiguous shards")
+    ap.add_argument("--merge", default="inline", choices=["inline", "off"], help="N > 1: all-gather of the top-k behind Refine, same stream")
+    ap.add_argument("--route-counters", action="store_true", help="also produce lastCandKept / rawSeen (forces the full select)")
     args = ap.parse_args()
 
     # Only the final JSON line may reach stdout: libraries (RCCL prints a version banner) write to fd 1 too.
@@ -95,179 +149,160 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = graft.load_package()
+    from fspann_amd import dist as fdist
+    F32 = pkg._native.F32
     wl = dict(WORKLOADS[args.workload])
     if args.batch > 0:
         wl["Q"] = args.batch
-    n, d, T, D, m, lam, B, Q, k = (wl[x] for x in ("n", "d", "T", "D", "m", "lam", "B", "Q", "k"))
+    n, d, T, D, m, lam, B, Qw, k = (wl[x] for x in ("n", "d", "T", "D", "m", "lam", "B", "Q", "k"))
     TD, W = T * D, (m * lam + 63) // 64
+    if args.scaling == "strong":       # one batch of Qw queries for the whole job, contiguous shards (last one padded)
+        Q = -(-Qw // world)
+        q_lo, q_hi = fdist.shard_bounds(Qw, world, rank)
+    else:
+        Q = Qw
+        q_lo, q_hi = 0, Q
+    q_live = q_hi - q_lo
+    extras = (world == 1) and not args.no_extras
+    dense = args.candidates == "dense"
 
-    # ---------------- synthetic data (same on every rank; queries differ per rank) ----------------
+    # ---------------- data + frozen index ----------------------------------------------------------------------------
     t0 = time.time()
-    rng = np.random.default_rng(args.seed)
-    X = rng.standard_normal((n, d), dtype=np.float32)
-    qrng = np.random.default_rng(args.seed + 1000 + rank)
     NB = max(1, args.query_batches)
-    Qall = qrng.standard_normal((NB, Q, d), dtype=np.float32)
-    Qh = Qall[0]
+    if args.scaling == "strong":
+        X, Qglob, data_desc = make_data(args.data, n, d, NB, Qw, args.seed, 0)      # the same global batches on every rank
+        Qall = np.zeros((NB, Q, d), np.float32)
+        Qall[:, :q_live] = Qglob[:, q_lo:q_hi]
+    else:
+        X, Qall, data_desc = make_data(args.data, n, d, NB, Q, args.seed, rank)
+    n = len(X)
     cfg = pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=lam, dim=d, seed=13, refinement_limit=B)
-    ctxs = []
-    # a second context (own HIP stream) is set up for the extra "pipelined" pass: steps alternate between two streams,
-    # so the latency-bound Route of one batch overlaps the HBM-bound Refine of the other
-    want_pipe = (world == 1) and not args.no_pipelined and args.streams == 1
-    for si in range(max(1, args.streams, 2 if want_pipe else 1)):
-        c_ = pkg.FspannContext(cfg, local_rank)
-        if si == 0:
-            c_.registry_initialize(X[:1000].astype(np.float64))   # GFunctionRegistry.initialize from the first 1000 vectors
-            c_.set_id_meta(n)
-            c_.build_index(X)                                      # GPU coding (MFMA pre-filter + exact re-check) + partition cut
-        else:                                                      # further streams import the frozen state
-            c_.set_gfunctions(*ctxs[0].get_gfunctions())
-            c_.set_id_meta(n)
-            for td in range(TD):
-                c_.set_index(td, **ctxs[0].get_index(td))
-            c_.finalize()
-        c_.store_set(X)                                            # plaintext store (decrypt stand-in), fp32
-        ctxs.append(c_)
-    ctx = ctxs[0]
+    ctx = pkg.FspannContext(cfg, local_rank)
+    ctx.registry_initialize(X[:1000].astype(np.float64))   # GFunctionRegistry.initialize from the first 1000 vectors
+    ctx.set_id_meta(n)
+    ctx.build_index(X)                                      # GPU coding (MFMA pre-filter + exact re-check) + partition cut
+    ctx.store_set(X)                                        # plaintext rows: source of the dense blocks / the store variant
+    ctxs = [ctx]
+    if extras:                                              # second context (own HIP stream) for the `pipelined` extra
+        c2 = pkg.FspannContext(cfg, local_rank)
+        c2.set_gfunctions(*ctx.get_gfunctions())
+        c2.set_id_meta(n)
+        for td in range(TD):
+            c2.set_index(td, **ctx.get_index(td))
+        c2.finalize()
+        c2.store_attach_dev(n, ctx.L.fspann_store_dev_ptr(ctx.handle, None), F32)     # same rows, no second copy
+        ctxs.append(c2)
     if rank == 0:
-        log(f"[bench] setup {time.time() - t0:.1f}s: n={n} d={d} T*D={TD} bits={m * lam} B={B} Q/GPU={Q} k={k}")
+        log(f"[bench] setup {time.time() - t0:.1f}s: n={n} d={d} T*D={TD} bits={m * lam} B={B} Q/GPU={Q} k={k} data={args.data}")
 
-    # ---------------- device buffers ------------------------------------------------------------------
+    # QSI's adaptive retry (QSI:327-337,444-447): one more pass with 10 probes when returned < K or decrypted < 10*K.
+    # With B < 10*K the second condition always holds (decrypted <= B), so every query takes both passes and the second
+    # one is the answer; with B >= 10*K (and >= K finite candidates, true for the synthetic data) it never triggers.
+    probe_passes = [-1, 10] if B < 10 * k else [-1]
+
+    # ---------------- device buffers -------------------------------------------------------------------------------------
     q_all = torch.from_numpy(Qall).to(dev)
-    q_dev = q_all[0]
-    from fspann_amd import dist as fdist
-
-    class _TorchEv:          # same interface over a default torch event (system-scope fence on record)
-        def __init__(self):
-            self.e = torch.cuda.Event()
-
-        def record(self, st):
-            self.e.record(st)
-
-        def wait(self, st):
-            st.wait_event(self.e)
-
-    def mkev():
-        if use_dist:
-            return fdist.DeviceEvent()        # device-scope release: no L2 writeback/invalidate per hand-off
-        return _TorchEv()
 
     def mkbufs():
         return dict(codes=torch.zeros((Q, TD, W), dtype=torch.int64, device=dev), bad=torch.zeros(Q, dtype=torch.int32, device=dev),
                     sel_ids=torch.full((Q, B), -1, dtype=torch.int32, device=dev), sel_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
                     kept=torch.zeros(Q, dtype=torch.int32, device=dev), raw=torch.zeros(Q, dtype=torch.int32, device=dev),
-                    cand=torch.zeros((Q, B, d), dtype=torch.float32, device=dev),
-                    # results are double-buffered so the all-gather of step i (side stream) overlaps step i+1
-                    # (ids and distances of one step live in ONE byte buffer: the merge is a single collective)
+                    cand=torch.zeros((Q, B, d), dtype=torch.float32, device=dev) if args.candidates == "gather" or extras else None,
+                    # packed (ids | distances) results, double-buffered; the merge is a single collective on them
                     topk=[fdist.TopkBuffer(Q, k, dev) for _ in range(2)],
                     out_cnt=torch.zeros(Q, dtype=torch.int32, device=dev), scored=torch.zeros(Q, dtype=torch.int32, device=dev),
-                    gathered=[fdist.GatheredTopk(world, Q, k, dev) for _ in range(2)] if use_dist else None,
-                    ev_done=[mkev() for _ in range(2)], ev_gath=[mkev() for _ in range(2)], nsteps=0)
+                    gathered=[fdist.GatheredTopk(world, Q, k, dev) for _ in range(2)] if use_dist else None, nsteps=0)
 
     bufs = [mkbufs() for _ in ctxs]
-    out_ids, out_dist = bufs[0]["topk"][0].ids, bufs[0]["topk"][0].dist
-    gathered = bufs[0]["gathered"][0] if use_dist else None
-    side = torch.cuda.Stream(device=dev) if use_dist else None
-    # the collective is issued straight through librccl when that works (host cost per call: us instead of ~80 us)
-    rccl = fdist.DirectRccl(world, rank, dev) if use_dist else None
-    if use_dist:
-        flag = torch.tensor([1 if rccl.ok else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks or none
-        if int(flag.item()) == 0:
-            rccl.ok = False
-    def merge(local, out, st):
-        """the ONE collective of the path, issued on stream `st`"""
-        if rccl.ok:
-            rccl.allgather_topk(local, out, st)
-        else:
-            with torch.cuda.stream(st):
-                fdist.allgather_topk(local, out)
-
-    gather_path = "ncclAllGather via librccl (direct)" if (use_dist and rccl.ok) else ("torch.distributed all_gather_into_tensor" if use_dist else None)
-    torch.cuda.synchronize()
-
     streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
-    F32 = pkg._native.F32
+
+    # dense candidate blocks: F_q of every distinct batch, packed ONCE before the timed region by the gather kernel — the
+    # device stand-in for the host's loadPointIfActive + decryptFromPoint (PIS:717-724, AesGcmCryptoService.java:126-166)
+    cand_all = None
+    if dense or extras:
+        try:
+            cand_all = torch.empty((NB, Q, B, d), dtype=torch.float32, device=dev)
+        except RuntimeError:
+            raise SystemExit(f"cannot hold {NB} dense candidate blocks ({NB * Q * B * d * 4 / 1e9:.1f} GB): lower --query-batches")
+        b0 = bufs[0]
+        for bi in range(NB):
+            qp = q_all[bi].data_ptr()
+            cand_all[bi].zero_()
+            torch.cuda.synchronize()
+            ctx.encode_dev(Q, qp, F32, b0["codes"].data_ptr(), 0, b0["bad"].data_ptr())
+            ctx.route_dev(Q, b0["codes"].data_ptr(), probe_passes[-1], B, B, b0["sel_ids"].data_ptr(), 0, b0["sel_cnt"].data_ptr(), 0, 0)
+            ctx.store_gather_dev(Q, b0["sel_ids"].data_ptr(), b0["sel_cnt"].data_ptr(), B, cand_all[bi].data_ptr())
+        ctx.sync()
+        if ctx.unmodelled_queries() != 0:
+            raise SystemExit("bench: a query's HashMap would have treeified a bin at this workload (Java order not modelled)")
+
+    comm = None
+    gather_path = None
+    if use_dist and args.merge != "off":
+        comm = fdist.LibComm(ctx, world, rank, dev)        # fspann_comm_* of the C library, bootstrapped over the torch group
+        gather_path = (f"fspann_allgather_topk_dev (ncclAllGather via {os.path.basename(comm.library)}) on the context's stream"
+                       if comm.ok else "torch.distributed all_gather_into_tensor")
+
+    def merge(b, par, stream):
+        """the ONE collective of the path, behind Refine on the same stream"""
+        if comm is None:
+            return
+        if comm.ok:
+            comm.allgather_topk(b["topk"][par], b["gathered"][par])
+        else:
+            with torch.cuda.stream(stream):
+                fdist.allgather_topk(b["topk"][par], b["gathered"][par])
+
+    torch.cuda.synchronize()
     step_no = [0]
-    merge_mode = [args.merge if args.merge != "auto" else "inline"]   # "inline" | "overlap"; "auto" is settled before the warmup
-    # QSI's adaptive retry (QSI:327-337,444-447): one more pass with 10 probes when returned < K or decrypted < 10*K.
-    # With B < 10*K the second condition always holds (decrypted <= B), so every query takes both passes and the second
-    # one is the answer; with B >= 10*K (and >= K finite candidates, true for the synthetic data) it never triggers.
-    probe_passes = [-1, 10] if B < 10 * k else [-1]
-    active = [max(1, args.streams)]          # contexts the steps alternate between
-    dense = (args.candidates == "dense")
+    active = [1]          # contexts the steps alternate between
 
-    def ev():
-        return torch.cuda.Event(enable_timing=True)
-
-    def step(events=None, batch=None, ref_only=False):
-        # events: 5 HIP events on the context's stream; ref_only = record just [3] and [4] (around the refinement scan)
+    def step(mode, events=None, batch=None):
+        """One pass of the hot path over one batch.  mode: dense | store | gather.  events: 5 torch events recorded around
+        the stages (untimed breakdown passes only)."""
         si = step_no[0] % active[0]
-        qp = q_all[(step_no[0] // active[0]) % NB].data_ptr() if batch is None else q_all[batch].data_ptr()
+        bi = (step_no[0] // active[0]) % NB if batch is None else batch
         step_no[0] += 1
+        qp = q_all[bi].data_ptr()
         cx, stream, b = ctxs[si], streams[si], bufs[si]
-        if events is None and not dense and not args.route_counters:
-            # the whole step in ONE library call (encode -> route(limit = B) -> refine from the store, stream order)
-            par = b["nsteps"] & 1
-            b["nsteps"] += 1
-            if use_dist and b["nsteps"] > 2 and merge_mode[0] != "inline":
-                b["ev_gath"][par].wait(stream)            # the all-gather that last read this result buffer has finished
+        par = b["nsteps"] & 1
+        b["nsteps"] += 1
+        tk = b["topk"][par]
+        if mode == "store" and events is None and not args.route_counters:
+            # the whole step in ONE library call (encode -> bounded select -> refine from the store, stream order)
             for pov in probe_passes:
-                cx.search_store_dev(Q, qp, F32, pov, B, k, b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(),
-                                    b["out_cnt"].data_ptr(), b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(),
-                                    b["bad"].data_ptr())
-            if use_dist and merge_mode[0] == "inline":
-                # the collective follows Refine on the SAME stream: no cross-stream events (each costs this stream two
-                # extra barrier packets, ~20 us per step on this runtime — more than the all-gather itself)
-                merge(b["topk"][par], b["gathered"][par], stream)
-                return
-            if use_dist:
-                b["ev_done"][par].record(stream)
-                b["ev_done"][par].wait(side)
-                merge(b["topk"][par], b["gathered"][par], side)
-                b["ev_gath"][par].record(side)
+                cx.search_store_dev(Q, qp, F32, pov, B, k, tk.ids.data_ptr(), tk.dist.data_ptr(), b["out_cnt"].data_ptr(),
+                                    b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), b["bad"].data_ptr())
+            merge(b, par, stream)
             return
         for pov in probe_passes[:-1]:   # first pass of the adaptive retry (see probe_passes); the stages below are the last pass
-            cx.search_store_dev(Q, qp, F32, pov, B, k, b["topk"][0].ids.data_ptr(), b["topk"][0].dist.data_ptr(),
-                                b["out_cnt"].data_ptr(), b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(),
-                                b["bad"].data_ptr())
-        if events is not None and not ref_only:
+            cx.search_store_dev(Q, qp, F32, pov, B, k, tk.ids.data_ptr(), tk.dist.data_ptr(), b["out_cnt"].data_ptr(),
+                                b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), b["bad"].data_ptr())
+        if events is not None:
             events[0].record(stream)
         cx.encode_dev(Q, qp, F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())
-        if events is not None and not ref_only:
+        if events is not None:
             events[1].record(stream)
-        # lastCandKept / rawSeen are profiler counters of the reference (QSI metrics), not inputs of Refine: they are
-        # only computed on request (--route-counters), which forces the full select over every probed partition
+        # lastCandKept / rawSeen are profiler counters of the reference (QSI metrics), not inputs of Refine: computed only
+        # on request (--route-counters), which forces the full select over every probed partition
         cx.route_dev(Q, b["codes"].data_ptr(), probe_passes[-1], B, B, b["sel_ids"].data_ptr(), 0, b["sel_cnt"].data_ptr(),
                      b["kept"].data_ptr() if args.route_counters else 0, b["raw"].data_ptr() if args.route_counters else 0)
-        if events is not None and not ref_only:
+        if events is not None:
             events[2].record(stream)
-        if dense:   # explicit stand-in for the host's load + decrypt: pack F_q rows into [Q][B][d]
+        if mode == "gather":
             cx.store_gather_dev(Q, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), B, b["cand"].data_ptr())
         if events is not None:
             events[3].record(stream)
-        par = b["nsteps"] & 1
-        b["nsteps"] += 1
-        if use_dist and b["nsteps"] > 2 and merge_mode[0] != "inline":
-            b["ev_gath"][par].wait(stream)            # the all-gather that last read this result buffer has finished
-        if dense:
-            cx.refine_dev(Q, qp, F32, b["cand"].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
-                          b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
-        else:       # candidate rows are read from the resident store by id inside the scan (each row once, no copy)
-            cx.refine_store_dev(Q, qp, F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k,
-                                b["topk"][par].ids.data_ptr(), b["topk"][par].dist.data_ptr(), b["out_cnt"].data_ptr(),
-                                b["scored"].data_ptr())
+        if mode == "store":
+            cx.refine_store_dev(Q, qp, F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k, tk.ids.data_ptr(), tk.dist.data_ptr(),
+                                b["out_cnt"].data_ptr(), b["scored"].data_ptr())
+        else:
+            cp = b["cand"].data_ptr() if mode == "gather" else cand_all[bi].data_ptr()
+            cx.refine_dev(Q, qp, F32, cp, F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k, tk.ids.data_ptr(), tk.dist.data_ptr(),
+                          b["out_cnt"].data_ptr(), b["scored"].data_ptr())
         if events is not None:
             events[4].record(stream)
-        if use_dist and merge_mode[0] == "inline":
-            merge(b["topk"][par], b["gathered"][par], stream)
-        elif use_dist:
-            # --merge overlap: the all-gather of [Q x k] (id, dist) per rank on a side stream, so that it overlaps the
-            # next step's kernels (two events per step; see --merge)
-            b["ev_done"][par].record(stream)
-            b["ev_done"][par].wait(side)
-            merge(b["topk"][par], b["gathered"][par], side)
-            b["ev_gath"][par].record(side)
+        merge(b, par, stream)
 
     def barrier():
         for c_ in ctxs:
@@ -276,153 +311,208 @@ def main():
         if use_dist:
             dist.barrier()
 
-    # --merge auto: which placement of the collective is faster depends on the all-gather latency of this node (ranks,
-    # xGMI hops) against the fixed cost of two cross-stream events; a short untimed trial decides, rank 0's verdict holds
-    merge_trial = None
-    if use_dist and args.merge == "auto":
-        trial = {}
-        for mode in ("inline", "overlap"):
-            merge_mode[0] = mode
-            for b_ in bufs:
-                b_["nsteps"] = 0
-            for _ in range(4):
-                step()
-            barrier()
-            t_t = time.perf_counter()
-            for _ in range(12):
-                step()
-            barrier()
-            trial[mode] = (time.perf_counter() - t_t) / 12
-        tt = torch.tensor([trial["inline"], trial["overlap"]], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)                     # slowest rank per mode
-        merge_mode[0] = "inline" if float(tt[0]) <= float(tt[1]) else "overlap"
-        merge_trial = "inline %.1f us/step, overlap %.1f us/step" % (float(tt[0]) * 1e6, float(tt[1]) * 1e6)
+    def timed(mode, steps, warmup, with_events=False):
+        """(elapsed seconds of `steps` steps, max over ranks; kernel-attached refine timing when asked)"""
         for b_ in bufs:
             b_["nsteps"] = 0
-        barrier()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-
-    evs = [[ev() for _ in range(5)] for _ in range(args.steps)]
-    barrier()
-    t_start = time.perf_counter()
-    # timed region: every TIMED_EVERY-th refinement-scan dispatch carries its own start/stop HIP events (kernel-attached, on the
-    # context's stream) -> roofline.  (An attached pair costs a few us of stream time, so not every dispatch gets one.)
-    TIMED_EVERY = max(2, args.steps // 8)     # about eight timed dispatches whatever --steps is
-    for c_ in ctxs[:active[0]]:
-        c_.refine_timing_begin(args.steps, TIMED_EVERY)
-    for i in range(args.steps):
-        step()
-    for c_ in ctxs:
-        c_.sync()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    rt = [c_.refine_timing_end() for c_ in ctxs[:active[0]]]
-    ref_ms_timed = sum(t for _, t in rt) / max(1, sum(n for n, _ in rt))          # kernel-attached events
-
-    # ---- stage breakdown: a separate, untimed pass with an event after every stage -----------------------------
-    nprof = min(args.steps, 20)
-    barrier()
-    for i in range(nprof):
-        step(evs[i])
-    barrier()
-
-    # ---- extra pass: the same steps alternating between two streams (reported, never `value`) ----
-    pipelined = None
-    if want_pipe:
-        active[0] = 2
         step_no[0] = 0
-        for b_ in bufs:
-            b_["nsteps"] = 0
-        for _ in range(max(2, args.warmup)):
-            step()
+        for _ in range(warmup):
+            step(mode)
         barrier()
-        t_p = time.perf_counter()
-        for i in range(args.steps):
-            step()
-        for c_ in ctxs:
+        every = max(2, steps // 8)                      # about eight timed dispatches whatever --steps is
+        if with_events:
+            for c_ in ctxs[:active[0]]:
+                c_.refine_timing_begin(steps, every)
+        t_s = time.perf_counter()
+        for _ in range(steps):
+            step(mode)
+        for c_ in ctxs[:active[0]]:
             c_.sync()
         torch.cuda.synchronize()
-        el_p = time.perf_counter() - t_p
-        pipelined = dict(streams=2, value=round(Q * args.steps / el_p, 1), unit="queries/s", ms_per_step=round(el_p * 1000.0 / args.steps, 4),
-                         note="same steps alternating between two contexts/HIP streams on this GPU: Route of one batch overlaps "
-                              "Refine of the other; kernel durations are no longer solo, so the roofline above is not taken here")
-        active[0] = max(1, args.streams)
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t_s
+        if use_dist:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        rt = [c_.refine_timing_end() for c_ in ctxs[:active[0]]] if with_events else None
+        return el, rt, every
 
-    # one more (untimed) step of batch 0 on context 0: its results are what recall and the CPU baseline are checked on
-    step_no[0] = 0
-    bufs[0]["nsteps"] = 0
-    barrier()
-    step(batch=0)
-    barrier()
+    # ---------------- the timed region ------------------------------------------------------------------------------------
+    mode = args.candidates
+    elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, with_events=True)
+    ref_launches = sum(x for x, _ in rt)
+    ref_ms = sum(t for _, t in rt) / max(1, ref_launches)          # kernel-attached HIP events, on the context's stream
+    ms_per_step = elapsed * 1000.0 / args.steps
+    q_job = Qw if args.scaling == "strong" else world * Q
+    qps = q_job * args.steps / elapsed
 
+    # ---------------- stage breakdown: a separate, untimed pass with an event after every stage ---------------------------
+    nprof = min(args.steps, 20)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(nprof)]
+    barrier()
+    for i in range(nprof):
+        step(mode, evs[i])
+    barrier()
     stage_ms = np.array([[evs[i][j].elapsed_time(evs[i][j + 1]) for j in range(4)] for i in range(nprof)])
     st_mean = stage_ms.mean(axis=0)
-    ms_per_step = elapsed * 1000.0 / args.steps
-    qps = world * Q * args.steps / elapsed
 
-    # ---------------- roofline of the refinement scan (north_star's HBM-bound kernel) -----------------
+    # ---------------- extra passes (N = 1; reported beside `value`, never as it) -------------------------------------------
+    variants, pipelined, hbm_proof, cfg4_shape, peak_measured = {}, None, None, None, None
+    if extras:
+        for vm, note in (("store", "trusted-HBM variant: Refine reads plaintext rows of an HBM-resident store by id (one library call per step); "
+                                   "production keeps decrypt on the host, so this is NOT the reference's boundary"),
+                         ("gather", "the [Q][B][d] block is packed inside the step by a gather kernel (device stand-in for load + decrypt), then scanned"),
+                         ("dense", "the [Q][B][d] block is resident before the step (SURVEY 8d kernel path)")):
+            if vm == mode:
+                continue
+            el_v, _, _ = timed(vm, args.steps, max(2, args.warmup))
+            variants[vm] = dict(value=round(Q * args.steps / el_v, 1), unit="queries/s", ms_per_step=round(el_v * 1000.0 / args.steps, 4), note=note)
+        active[0] = 2
+        el_p, _, _ = timed(mode, args.steps, max(2, args.warmup))
+        active[0] = 1
+        pipelined = dict(streams=2, value=round(Q * args.steps / el_p, 1), unit="queries/s", ms_per_step=round(el_p * 1000.0 / args.steps, 4),
+                         note="same steps alternating between two contexts/HIP streams on this GPU: Route of one batch overlaps Refine of "
+                              "the other; kernel durations are no longer solo, so the roofline is not taken here")
+
+    # one more (untimed) step of batch 0 on context 0: its results are what recall and the CPU baseline are checked on
+    for b_ in bufs:
+        b_["nsteps"] = 0
+    step_no[0] = 0
+    barrier()
+    step(mode, batch=0)
+    barrier()
+    out_ids, out_dist = bufs[0]["topk"][0].ids, bufs[0]["topk"][0].dist
+    got_ids, got_dist = out_ids.cpu().numpy(), out_dist.cpu().numpy()
+    if ctx.unmodelled_queries() != 0:
+        raise SystemExit("bench: a query's HashMap would have treeified a bin during the run (Java order not modelled)")
+
+    # ---------------- roofline of the refinement scan (north_star's HBM-bound kernel) ---------------------------------------
     # algorithmic bytes per launch (SURVEY §8d): Q * (B*d*4 + d*4 + k*8)
     ref_bytes = Q * (B * d * 4 + d * 4 + k * 8)
-    ref_ms = ref_ms_timed                  # the refinement scan's launches inside the timed region
     achieved = ref_bytes / (ref_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "refine_traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            tj = tj.get(args.candidates, {})
+            tj = json.load(open(tpath)).get(mode, {})
             if tj.get("workload") == args.workload and tj.get("Q") == Q:
-                traffic = tj.get("hbm_bytes_per_launch")
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         except Exception:
             traffic = None
-    kname = "refine_scan_kernel<float,float,32,true,%s>" % ("false" if dense else "true")
-    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5), launches=sum(n for n, _ in rt),
+    if extras:
+        peak_measured = round(ctx.hbm_read_peak(1 << 32, 5), 1)      # pure 16-byte-load kernel over 4 GiB, best of 5
+        # (a) the same scan reading 1024 x 256 random rows of an 8 M x 128 (4.1 GB) store: 134 MB per launch out of 4.1 GB
+        NS = 8_000_000
+        big = torch.randn((NS, d), dtype=torch.float32, device=dev)
+        rid = torch.randint(0, NS, (8, Q, B), dtype=torch.int32, device=dev)
+        cnt = torch.full((Q,), B, dtype=torch.int32, device=dev)
+        b0 = bufs[0]
+        torch.cuda.synchronize()
+        with pkg.FspannContext(cfg, local_rank) as cp:         # Refine needs no index: a bare context over the big store
+            cp.store_attach_dev(NS, big.data_ptr(), F32)
+
+            def rs(i):
+                cp.refine_store_dev(Q, q_all[0].data_ptr(), F32, B, rid[i % 8].data_ptr(), cnt.data_ptr(), k, b0["topk"][1].ids.data_ptr(),
+                                    b0["topk"][1].dist.data_ptr(), b0["out_cnt"].data_ptr(), b0["scored"].data_ptr())
+            for i in range(4):
+                rs(i)
+            cp.sync()
+            cp.refine_timing_begin(40, 1)
+            for i in range(40):
+                rs(i)
+            nl, tms = cp.refine_timing_end()
+        del big, rid
+        hp_ms = tms / max(1, nl)
+        hbm_proof = dict(kernel="refine_scan_kernel<float,float,32,true,true>", store_rows=NS, store_bytes=NS * d * 4, launches=nl,
+                         avg_launch_ms=round(hp_ms, 5), achieved=round(ref_bytes / (hp_ms * 1e-3) / 1e9, 1),
+                         frac=round(ref_bytes / (hp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         note="1024 x 256 uniformly random rows of a 4.1 GB store per launch, 8 id sets cycled: at most 6 % of a launch's rows "
+                              "can sit in the 256 MiB Infinity Cache")
+        # (b) BASELINE config #4's refine shape: d = 768, B = 1024 -> four 256-row chunks per query + refine_merge_kernel
+        d4, B4 = 768, 1024
+        cfg4 = pkg.PaperRuntimeConfig(tables=1, divisions=1, m=8, lambda_=2, dim=d4, refinement_limit=B4)
+        with pkg.FspannContext(cfg4, local_rank) as c4:
+            cand4 = torch.randn((2, Q, B4, d4), dtype=torch.float32, device=dev)          # 2 x 3.2 GB
+            q4 = torch.randn((Q, d4), dtype=torch.float32, device=dev)
+            ids4 = torch.arange(Q * B4, dtype=torch.int32, device=dev).view(Q, B4)
+            cnt4 = torch.full((Q,), B4, dtype=torch.int32, device=dev)
+            oi4 = torch.zeros((Q, k), dtype=torch.int32, device=dev)
+            od4 = torch.zeros((Q, k), dtype=torch.float64, device=dev)
+            oc4 = torch.zeros(Q, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            s4 = torch.cuda.ExternalStream(c4.stream, device=dev)
+
+            def r4(i):
+                c4.refine_dev(Q, q4.data_ptr(), F32, cand4[i & 1].data_ptr(), F32, B4, ids4.data_ptr(), cnt4.data_ptr(), k, oi4.data_ptr(),
+                              od4.data_ptr(), oc4.data_ptr(), 0)
+            for i in range(2):
+                r4(i)
+            c4.sync()
+            c4.refine_timing_begin(12, 1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s4)
+            for i in range(12):
+                r4(i)
+            e1.record(s4)
+            nl4, tms4 = c4.refine_timing_end()
+            bytes4 = Q * (B4 * d4 * 4 + d4 * 4 + k * 8)
+            scan_ms, call_ms = tms4 / max(1, nl4), e0.elapsed_time(e1) / 12
+            cfg4_shape = dict(kernel="refine_scan_kernel<float,float,32,true,false> x 4 chunks + refine_merge_kernel", Q=Q, B=B4, dim=d4,
+                              algorithmic_bytes_per_launch=bytes4, scan_launch_ms=round(scan_ms, 4), scan_plus_merge_ms=round(call_ms, 4),
+                              achieved=round(bytes4 / (scan_ms * 1e-3) / 1e9, 1), frac=round(bytes4 / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              note="two 3.2 GB blocks alternate; events attached to the scan kernel; scan_plus_merge_ms = whole fspann_refine_dev call")
+            del cand4
+    kname = "refine_scan_kernel<float,float,32,true,%s>" % ("true" if mode == "store" else "false")
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, peak_spec=HBM_PEAK_GBS,
+                    peak_measured=peak_measured, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                    frac_of_measured=round(achieved / peak_measured, 4) if peak_measured else None,
+                    traffic=traffic, traffic_source=traffic_src,
+                    algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5), launches=ref_launches,
+                    working_set_bytes=(NB * Q * B * d * 4) if mode == "dense" else n * d * 4,
                     timing="HIP start/stop events attached to every %d-th refine_scan_kernel dispatch of the timed region "
                            "(hipExtLaunchKernel, on the context's stream)" % TIMED_EVERY,
-                    bracket_ms=round(float(st_mean[3]), 5))
+                    bracket_ms=round(float(st_mean[3]), 5), hbm_proof=hbm_proof, cfg4_shape=cfg4_shape)
 
-    # Route (probe + select) is the longest stage but is bound by dependent L2 rounds and LDS atomics, not by HBM or
-    # MFMA; its algorithmic bytes (per (t,d) search + rep/id-range fetch + P*S ids) are reported for scale.
+    # Route (probe + select) is bound by dependent L2 rounds and LDS atomics, not by HBM or MFMA; its algorithmic bytes
+    # (SURVEY §8d: per (t,d) search + rep/id-range fetch + P*S ids) are reported for scale.
     P_, S_ = 5, 64
     nparts = (n + S_ - 1) // S_
     levels = max(1, int(np.ceil(np.log(max(nparts, 2)) / np.log(16))))
     route_bytes = Q * (TD * (levels * 16 * 16 + (2 * P_ - 1) * (8 * W + 8) + P_ * S_ * 4) + B * 4)
     route_ms = float(st_mean[1])
     rinfo = ctx.last_route_info()
-    route_info = dict(kernels="route_probe_kernel + " + ("route_select_lazy_kernel<256> (bounded select; %d of %d queries handed to the full select)"
-                                                         % (rinfo["overflowed"], Q) if rinfo["lazy"] else "route_select_kernel<true,512>"), bound="L2 latency + LDS atomics (integer)",
-                      avg_ms=round(route_ms, 5), algorithmic_bytes_per_launch=int(route_bytes),
+    route_info = dict(kernels=("route_select_lazy_kernel<256> with the probe fused in (bounded select; %d of %d queries handed to the full select)"
+                               % (rinfo["overflowed"], Q)) if rinfo["lazy"] else "route_probe_kernel + route_select_kernel<true,512>",
+                      bound="L2 latency + LDS atomics (integer)", avg_ms=round(route_ms, 5), algorithmic_bytes_per_launch=int(route_bytes),
                       achieved_GBs=round(route_bytes / (route_ms * 1e-3) / 1e9, 1))
 
-    # ---------------- recall@10 vs exact kNN of the synthetic set (reported, never assumed) ------------
-    recall = None
+    # ---------------- recall@10 + distance ratio vs exact kNN of the data set (reported, never assumed) ------------------
+    recall = ratio = None
     if rank == 0:
         with torch.no_grad():
             Xd = torch.from_numpy(X).to(dev)
             xx = (Xd * Xd).sum(1)
             gt = []
             for s in range(0, Q, 256):
-                qq = q_dev[s:s + 256]
+                qq = q_all[0][s:s + 256]
                 dd = xx[None, :] - 2.0 * (qq @ Xd.T)
                 gt.append(torch.topk(dd, k, dim=1, largest=False).indices)
             gt = torch.cat(gt).cpu().numpy()
-            got = out_ids.cpu().numpy()
-            recall = float(np.mean([len(set(gt[i]) & set(got[i])) / k for i in range(Q)]))
             del Xd
+        nv = q_live if args.scaling == "strong" else Q
+        recall = float(np.mean([len(set(gt[i]) & set(got_ids[i])) / k for i in range(nv)]))
+        # distance ratio (ForwardSecureANNSystem.java:798-823): mean over ranks i < k of d(q, ann_i) / d(q, gt_i), queries with k results
+        rsum = []
+        for i in range(nv):
+            if (got_ids[i] >= 0).all():
+                dg = np.sqrt(((Qall[0, i][None, :].astype(np.float64) - X[gt[i]].astype(np.float64)) ** 2).sum(1))
+                if (dg > 0).all():
+                    rsum.append(float(np.mean(got_dist[i] / dg)))
+        ratio = float(np.mean(rsum)) if rsum else None
 
-    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) -----------
+    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) --------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         O = graft.load_oracle()
@@ -438,8 +528,7 @@ def main():
         del X64
         index_same = all(np.array_equal(ctx.get_index(td)[k_], v_) for td in range(TD) for k_, v_ in o.get_index(td).items())
         ns = min(args.cpu_sample, Q)
-        qs = Qh[:ns].astype(np.float64)
-        t1 = time.perf_counter()
+        qs = Qall[0][:ns].astype(np.float64)
         cds = o.encode(qs[:8])  # warm
         ref = o.search(qs[:8], k, codes=cds, threads=1)
         t1 = time.perf_counter()
@@ -452,8 +541,7 @@ def main():
             if time.perf_counter() - t1 > 10.0 or reps >= 50:
                 break
         cpu_s = time.perf_counter() - t1
-        same = bool(np.array_equal(ref["ids"], out_ids.cpu().numpy()[:ns]) and
-                    np.array_equal(ref["dist"], out_dist.cpu().numpy()[:ns]))
+        same = bool(np.array_equal(ref["ids"], got_ids[:ns]) and np.array_equal(ref["dist"], got_dist[:ns]))
         if o.unmodelled:
             raise SystemExit("bench: a HashMap bin treeified in the oracle at this workload: the checker has no pinned order")
         if not (same and index_same):
@@ -463,24 +551,29 @@ def main():
                           f"no AES/RocksDB), C++ oracle single thread; host has {os.cpu_count()} logical cores",
                    matches_gpu=same, index_matches_gpu=bool(index_same), oracle_unmodelled=bool(o.unmodelled),
                    oracle_index_build_s=round(t_ob, 1))
-        # the same port over the host cores this GPU's share allows (queries are independent: threads over queries)
-        nthr = max(1, min(16, os.cpu_count() or 1))
+        # the same port over ALL host cores this process may use (queries are independent: threads over queries, encode too)
+        try:
+            nthr = len(os.sched_getaffinity(0))
+        except AttributeError:
+            nthr = os.cpu_count() or 1
         if nthr > 1:
+            qall64 = Qall[:4].reshape(-1, d).astype(np.float64)       # 4 batches: enough work per thread
+            o.search(qall64[:256], k, threads=nthr)
             t2 = time.perf_counter()
             reps2, done2 = 0, 0
             while True:
-                cds = o.encode(qs)
-                o.search(qs, k, codes=cds, threads=nthr)
+                o.search(qall64, k, threads=nthr)                      # encode + Route + Refine, all threaded over queries
                 reps2 += 1
-                done2 += ns
+                done2 += len(qall64)
                 if time.perf_counter() - t2 > 5.0 or reps2 >= 200:
                     break
-            cpu["multi_thread"] = dict(value=round(done2 / (time.perf_counter() - t2), 1), unit="queries/s", cores=nthr,
-                                       note="Route + Refine threaded over queries, encode single-threaded")
+            cpu["all_cores"] = dict(value=round(done2 / (time.perf_counter() - t2), 1), unit="queries/s", cores=nthr,
+                                    note="the same port, OpenMP over queries on every core this process may use")
 
     if rank == 0:
         out = {
-            "metric": "queries/sec @ recall@10, SIFT-1M d=128 B=256",
+            "metric": ("queries/sec @ recall@10, SIFT-1M-shaped synthetic data d=128 B=256" if args.data in ("gaussian", "clustered")
+                       else "queries/sec @ recall@10, d=%d B=%d" % (d, B)),
             "value": round(qps, 1),
             "unit": "queries/s",
             "n_gpus": world,
@@ -488,20 +581,25 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic N(0,1) fp32 vectors (SIFT-1M shape), exact-kNN ground truth of the synthetic set",
+            "data": data_desc + ", exact-kNN ground truth of the same set",
             "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
-                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "distinct_query_batches": NB, "route_counters": bool(args.route_counters), "passes_per_step": len(probe_passes),
-                       "parallelism": f"query-sharded x{world}, index replicated", "merge": (gather_path + (", same stream" if merge_mode[0] == "inline" else ", side stream") + (" (auto: %s)" % merge_trial if merge_trial else "")) if use_dist else None, "streams_per_gpu": active[0],
-                       "candidates": "rows read from the HBM-resident plaintext store by id inside the refine scan" if not dense
-                       else "rows packed into [Q][B][d] by a gather kernel (host decrypt stand-in), then scanned"},
+                       "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "queries_per_step": q_job,
+                       "distinct_query_batches": NB, "route_counters": bool(args.route_counters), "passes_per_step": len(probe_passes),
+                       "parallelism": f"query-sharded x{world}, index replicated", "merge": gather_path, "streams_per_gpu": 1,
+                       "candidates": {"dense": "kernel path (SURVEY 8d): [Q][B][d] blocks of decrypted candidate rows resident in HBM before the timed "
+                                               "region (packed once per distinct batch), scanned by refine_scan_kernel",
+                                      "store": "trusted-HBM variant: rows read from an HBM-resident plaintext store by id inside the refine scan",
+                                      "gather": "rows packed into [Q][B][d] by a gather kernel inside the step, then scanned"}[mode]},
             "recall_at_10": recall,
+            "distance_ratio_at_10": ratio,
             "stages_ms": {"encode": round(float(st_mean[0]), 5), "route_select": round(float(st_mean[1]), 5),
                           "stage_candidates": round(float(st_mean[2]), 5), "refine_topk": round(float(st_mean[3]), 5)},
             "roofline": roofline,
             "route_stage": route_info,
+            "variants": variants or None,
             "pipelined": pipelined,
             "cpu_baseline": cpu,
         }
@@ -509,14 +607,15 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if use_dist and rank == 0:
+    if use_dist and comm is not None and rank == 0:
         # merged result = every rank's top-k in rank order; rank 0's own slice must be intact
-        g_ids, g_dist = gathered.split()
+        g_ids, g_dist = bufs[0]["gathered"][0].split()
         assert torch.equal(g_ids[:Q], out_ids) and torch.equal(g_dist[:Q], out_dist)
-    for c_ in ctxs:
+    if comm is not None:
+        comm.close()
+    for c_ in ctxs[::-1]:
         c_.close()
     if use_dist:
-        rccl.close()
         dist.destroy_process_group()
 
 

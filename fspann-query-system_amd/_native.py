@@ -15,7 +15,7 @@ _SO = os.path.join(_HERE, "libfspann_hip.so")
 _SRC = os.path.join(_HERE, "csrc")
 
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-pthread"]
+               "-Wall", "-Wno-unused-function", "-pthread", "-ldl"]
 
 OK, E_STATE, E_ARG, E_NULL, E_DEVICE, E_NOMEM, E_RANGE = 0, -1, -2, -3, -4, -5, -6
 F32, F64 = 0, 1
@@ -122,8 +122,18 @@ _SIGS = {
     "fspann_refine_timing_end": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_double)]),
     "fspann_search_store_dev": (_i, [_vp, _i64, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fspann_store_set": (_i, [_vp, _i64, _vp, _i]),
+    "fspann_store_attach_dev": (_i, [_vp, _i64, _vp, _i]),
     "fspann_store_gather_dev": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "fspann_store_dev_ptr": (_vp, [_vp, C.POINTER(_i)]),
+    "fspann_topk_bytes": (_sz, [_i64, _i]),
+    "fspann_topk_dist_offset": (_sz, [_i64, _i]),
+    "fspann_comm_available": (_i, []),
+    "fspann_comm_unique_id": (_i, [_vp]),
+    "fspann_comm_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "fspann_comm_destroy": (_i, [_vp]),
+    "fspann_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_char_p)]),
+    "fspann_allgather_topk_dev": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "fspann_hbm_read_peak": (_i, [_vp, _sz, _i, C.POINTER(C.c_double)]),
     "fspann_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "fspann_dev_free": (_i, [_vp, _vp]),
     "fspann_h2d": (_i, [_vp, _vp, _vp, _sz]),

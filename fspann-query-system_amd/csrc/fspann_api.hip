@@ -9,6 +9,7 @@
 #include <new>
 #include <numeric>
 
+#include "comm.hip.h"
 #include "encode.hip.h"
 #include "refine.hip.h"
 #include "route.hip.h"
@@ -482,7 +483,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_dev(c->ws_fix.p);
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits); free_devt(c->d_unmodelled);
-    free_dev(c->d_store);
+    if (c->store_owned) free_dev(c->d_store);
     free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
@@ -1068,9 +1069,30 @@ int fspann_store_set(fspann_ctx* c, int64_t n, const void* vectors, int dtype) {
     if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
     if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
     const size_t bytes = static_cast<size_t>(n) * c->cfg.dim * (dtype == FSPANN_F64 ? 8 : 4);
-    free_dev(c->d_store);
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    if (c->store_owned) free_dev(c->d_store);
+    c->d_store = nullptr;
+    c->store_n = 0;
     FSP_HIP(hipMalloc(&c->d_store, bytes));
+    c->store_owned = true;
     FSP_HIP(hipMemcpy(c->d_store, vectors, bytes, hipMemcpyHostToDevice));
+    c->store_dtype = dtype;
+    c->store_n = n;
+    return FSPANN_OK;
+}
+
+// The same store over rows that already live in HBM (caller-owned, e.g. a tensor): no copy; the caller keeps the
+// memory alive and unchanged while the context refers to it (until the next store_set / store_attach / ctx_destroy).
+int fspann_store_attach_dev(fspann_ctx* c, int64_t n, const void* vectors_dev, int dtype) {
+    CHECK_CTX(c);
+    if (!vectors_dev) return fail(FSPANN_E_NULL, "vectors is null");
+    if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
+    if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+    if (reinterpret_cast<uintptr_t>(vectors_dev) & 15) return fail(FSPANN_E_ARG, "store rows must be 16-byte aligned");
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    if (c->store_owned) free_dev(c->d_store);
+    c->d_store = const_cast<void*>(vectors_dev);
+    c->store_owned = false;
     c->store_dtype = dtype;
     c->store_n = n;
     return FSPANN_OK;
@@ -1285,6 +1307,133 @@ int fspann_debug_route_stamps(fspann_ctx* c, void* dev_ptr) {
     return FSPANN_OK;
 }
 #endif
+
+// ---- multi-GPU merge: one RCCL all-gather of the packed per-rank top-k -------------------------------
+size_t fspann_topk_bytes(int64_t nq, int k) {
+    if (nq < 0 || k <= 0) return 0;
+    const size_t idb = (static_cast<size_t>(nq) * k * 4 + 7) & ~size_t(7);     // keeps the fp64 part 8-byte aligned
+    return idb + static_cast<size_t>(nq) * k * 8;
+}
+size_t fspann_topk_dist_offset(int64_t nq, int k) {
+    if (nq < 0 || k <= 0) return 0;
+    return (static_cast<size_t>(nq) * k * 4 + 7) & ~size_t(7);
+}
+
+int fspann_comm_available(void) { return rccl_api() ? 1 : 0; }
+
+int fspann_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(FSPANN_E_NULL, "id_out is null");
+    RcclApi* a = rccl_api();
+    if (!a) return fail(FSPANN_E_STATE, "librccl not found (set FSPANN_RCCL_LIB): %s", dlerror() ? dlerror() : "no candidate loaded");
+    RcclApi::UniqueId id;
+    const int rc = a->GetUniqueId(&id);
+    if (rc != 0) return fail(FSPANN_E_DEVICE, "ncclGetUniqueId: %s", rccl_err(a, rc));
+    std::memcpy(id_out, &id, sizeof(id));
+    return FSPANN_OK;
+}
+
+int fspann_comm_create(fspann_ctx* c, const void* unique_id, int world, int rank, fspann_comm** out) {
+    CHECK_CTX(c);
+    if (!unique_id || !out) return fail(FSPANN_E_NULL, "unique_id/out is null");
+    *out = nullptr;
+    if (world <= 0 || rank < 0 || rank >= world) return fail(FSPANN_E_ARG, "bad world %d / rank %d", world, rank);
+    RcclApi* a = rccl_api();
+    if (!a) return fail(FSPANN_E_STATE, "librccl not found (set FSPANN_RCCL_LIB)");
+    RcclApi::UniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    fspann_comm* m = new (std::nothrow) fspann_comm();
+    if (!m) return fail(FSPANN_E_NOMEM, "out of host memory");
+    const int rc = a->CommInitRank(&m->nccl, world, id, rank);     // on the context's device (CHECK_CTX made it current)
+    if (rc != 0) {
+        delete m;
+        return fail(FSPANN_E_DEVICE, "ncclCommInitRank(world %d, rank %d): %s", world, rank, rccl_err(a, rc));
+    }
+    m->ctx = c; m->world = world; m->rank = rank;
+    *out = m;
+    return FSPANN_OK;
+}
+
+int fspann_comm_destroy(fspann_comm* m) {
+    if (!m) return FSPANN_OK;
+    RcclApi* a = rccl_api();
+    if (a && m->nccl) {
+        if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
+        (void)a->CommDestroy(m->nccl);
+    }
+    delete m;
+    return FSPANN_OK;
+}
+
+int fspann_comm_info(fspann_comm* m, int* world, int* rank, const char** library) {
+    if (!m) return fail(FSPANN_E_NULL, "comm is null");
+    if (world) *world = m->world;
+    if (rank) *rank = m->rank;
+    if (library) { RcclApi* a = rccl_api(); *library = a ? a->path.c_str() : ""; }
+    return FSPANN_OK;
+}
+
+// gathered_dev = world x fspann_topk_bytes(nq_local, k), in rank order = global query order when the batch was cut into
+// contiguous equal shards (the last one padded with id -1 / +inf, which Refine writes for missing results anyway).
+int fspann_allgather_topk_dev(fspann_comm* m, int64_t nq_local, int k, const void* local_packed_dev, void* gathered_dev) {
+    if (!m || !m->ctx) return fail(FSPANN_E_NULL, "comm is null");
+    CHECK_CTX(m->ctx);
+    if (!local_packed_dev || !gathered_dev) return fail(FSPANN_E_NULL, "top-k buffer is null");
+    const size_t nb = fspann_topk_bytes(nq_local, k);
+    if (nb == 0) return fail(FSPANN_E_ARG, "nq_local < 0 or k <= 0");
+    RcclApi* a = rccl_api();
+    if (!a) return fail(FSPANN_E_STATE, "librccl not found");
+    const int rc = a->AllGather(local_packed_dev, gathered_dev, nb, 0 /* ncclInt8 */, m->nccl, m->ctx->stream);
+    if (rc != 0) return fail(FSPANN_E_DEVICE, "ncclAllGather: %s", rccl_err(a, rc));
+    return FSPANN_OK;
+}
+
+// Measurement aid (bench.py `roofline.peak_measured`): the rate at which THIS device streams `bytes` of HBM through a
+// pure 16-byte-load kernel (buffer owned by the library, larger than the 256 MiB Infinity Cache when bytes says so).
+}  // extern "C"
+namespace {
+__global__ __launch_bounds__(256) void hbm_read_kernel(const uint4* __restrict__ p, size_t n16, unsigned long long* __restrict__ sink) {
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = p[i];
+        acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) atomicAdd(sink, 1ull);   // keeps the loads alive; practically never taken
+}
+}  // namespace
+extern "C" {
+int fspann_hbm_read_peak(fspann_ctx* c, size_t bytes, int reps, double* gb_per_s) {
+    CHECK_CTX(c);
+    if (!gb_per_s || reps <= 0 || bytes < (1u << 20)) return fail(FSPANN_E_ARG, "bytes < 1 MiB, reps <= 0 or null output");
+    void* buf = nullptr;
+    unsigned long long* sink = nullptr;
+    FSP_HIP(hipMalloc(&buf, bytes));
+    if (hipMalloc(&sink, 8) != hipSuccess) { (void)hipFree(buf); return fail(FSPANN_E_NOMEM, "hipMalloc failed"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = FSPANN_OK;
+    do {
+        if (hipMemsetAsync(buf, 0x5A, bytes, c->stream) != hipSuccess || hipMemsetAsync(sink, 0, 8, c->stream) != hipSuccess ||
+            hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = fail(FSPANN_E_DEVICE, "setup failed"); break; }
+        const unsigned grid = static_cast<unsigned>(c->num_cus) * 8;
+        hipLaunchKernelGGL(hbm_read_kernel, dim3(grid), dim3(256), 0, c->stream, static_cast<const uint4*>(buf), bytes / 16, sink);   // warm-up
+        double best = 0.0;
+        for (int r = 0; r < reps; r++) {
+            (void)hipEventRecord(e0, c->stream);
+            hipLaunchKernelGGL(hbm_read_kernel, dim3(grid), dim3(256), 0, c->stream, static_cast<const uint4*>(buf), bytes / 16, sink);
+            (void)hipEventRecord(e1, c->stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(FSPANN_E_DEVICE, "hbm_read_kernel failed"); break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms > 0.f) best = std::max(best, static_cast<double>(bytes) / (ms * 1e-3) / 1e9);
+        }
+        *gb_per_s = best;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    (void)hipFree(sink);
+    return rc;
+}
 
 // ---- device memory helpers -----------------------------------------------------------------
 int fspann_dev_alloc(fspann_ctx* c, size_t bytes, void** out) {

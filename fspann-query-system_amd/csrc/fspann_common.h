@@ -137,6 +137,7 @@ struct fspann_ctx {
 
     // plaintext store (test / bench harness)
     void* d_store = nullptr;
+    bool store_owned = false;        // false: rows attached from caller-owned device memory (fspann_store_attach_dev)
     int store_dtype = FSPANN_F32;
     int64_t store_n = 0;
 

@@ -30,7 +30,7 @@ class TopkBuffer:
     def __init__(self, q: int, k: int, device="cpu"):
         import torch
         self.q, self.k = q, k
-        self.id_bytes = ((q * k * 4 + 7) // 8) * 8          # keep the fp64 part 8-byte aligned
+        self.id_bytes = ((q * k * 4 + 7) // 8) * 8          # == fspann_topk_dist_offset(q, k): the library's packed layout
         self.nbytes = self.id_bytes + q * k * 8
         self.raw = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.ids = self.raw[: q * k * 4].view(torch.int32).view(q, k)
@@ -62,95 +62,87 @@ def allgather_topk(local: TopkBuffer, out: GatheredTopk, group=None):
     return out
 
 
-class DirectRccl:
-    """The same all-gather issued straight through librccl (ncclAllGather on a given HIP stream): a few microseconds of
-    host time per call instead of the ~80 us torch.distributed spends in Python/ProcessGroup bookkeeping, which at
-    ~100 us per step is what limits a rank.  The communicator is bootstrapped over the existing torch.distributed group
-    (rank 0's ncclUniqueId is broadcast), lives next to torch's own, and is verified once against
-    `all_gather_into_tensor`; any failure leaves `ok = False` and the caller stays on torch.distributed.
-    """
+class LibComm:
+    """The merge collective of the C library (`fspann_comm_*`, include/fspann.h): ncclAllGather on the context's own
+    stream, a few microseconds of host time per call (torch.distributed spends ~80 us per call in ProcessGroup
+    bookkeeping).  This class only does the BOOTSTRAP over an existing torch.distributed group — shipping rank 0's
+    unique id — which a JVM deployment does over its own transport; every step that can fail on one rank alone is
+    followed by an agreement over the bootstrap group, so all ranks end up with `ok` True or all with False
+    (then the caller stays on `allgather_topk` above) and nobody is left waiting inside a collective."""
 
-    def __init__(self, world: int, rank: int, device):
+    def __init__(self, ctx, world: int, rank: int, device="cpu", group=None):
         import ctypes as C
-        import os
+        import sys
         import torch
         import torch.distributed as dist
+        from . import _native as N
         self.ok = False
-        self._C = C
+        self.ctx, self.world, self.rank = ctx, world, rank
+        self._h = None
+        self._L = L = N.lib()
+
+        def agree(flag: bool) -> bool:
+            f = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+            return int(f.item()) == 1
+
+        def note(msg):
+            print(f"[fspann] library collective disabled: {msg}", file=sys.stderr)
+
         try:
-            # every step below is taken by all ranks or by none (a rank that dropped out alone would leave the others
-            # waiting in a collective): local failures are agreed on through the existing group first
-            def all_agree(flag: bool) -> bool:
-                f = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
-                dist.all_reduce(f, op=dist.ReduceOp.MIN)
-                return int(f.item()) == 1
-
-            class UniqueId(C.Structure):
-                _fields_ = [("internal", C.c_char * 128)]
-
-            loaded = False
-            try:
-                if os.environ.get("FSPANN_DIRECT_RCCL", "1") != "0":
-                    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-                    self.lib = C.CDLL(path)          # the instance torch already loaded
-                    self.lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
-                    self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-                    self.lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
-                    self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
-                    loaded = True
-            except OSError:
-                loaded = False
-            if not all_agree(loaded):
-                return
-            uid = UniqueId()
+            if not agree(bool(L.fspann_comm_available())):           # librccl missing on some rank: nobody enters the create
+                return note("librccl not found on every rank")
+            uid = (C.c_char * 128)()
             status = 1
-            if rank == 0 and self.lib.ncclGetUniqueId(C.byref(uid)) != 0:
+            if rank == 0 and L.fspann_comm_unique_id(uid) != 0:
                 status = 0
-            payload = (bytes(bytearray(uid)) if rank == 0 else bytes(128)) + bytes([status])
-            t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
-            dist.broadcast(t, src=0)
-            raw = bytes(t.cpu().numpy().tobytes())
-            if raw[128] != 1:
-                return
-            C.memmove(C.byref(uid), raw[:128], 128)
-            self.comm = C.c_void_p()
-            with torch.cuda.device(device):
-                rc = self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
-            if rc != 0:
-                raise RuntimeError(f"ncclCommInitRank -> {rc}")
-            self.world, self.rank, self.device = world, rank, device
+            t = torch.frombuffer(bytearray(bytes(uid) + bytes([status])), dtype=torch.uint8).to(device)
+            dist.broadcast(t, src=0, group=group)
+            raw = t.cpu().numpy().tobytes()
+            if raw[128] != 1:                                         # the same byte on every rank
+                return note("ncclGetUniqueId failed on rank 0")
+            h = C.c_void_p()
+            rc = L.fspann_comm_create(ctx.handle, raw[:128], world, rank, C.byref(h))
+            if rc == 0:
+                self._h = h
+            if not agree(rc == 0):
+                self.close()
+                return note("ncclCommInitRank failed on some rank")
             # one verified exchange before anything relies on it
-            probe = torch.arange(rank * 1000, rank * 1000 + 256, dtype=torch.int32, device=device).view(torch.uint8)
-            got = torch.zeros(world * probe.numel(), dtype=torch.uint8, device=device)
+            k, nq = 3, 5
+            nb = int(L.fspann_topk_bytes(nq, k))
+            probe = ((torch.arange(nb, dtype=torch.int32, device=device) * 7 + rank * 131) % 251).to(torch.uint8)
+            got = torch.zeros(world * nb, dtype=torch.uint8, device=device)
             ref = torch.zeros_like(got)
-            s = torch.cuda.current_stream(device)
-            self.allgather_bytes(probe, got, s)
-            s.synchronize()
-            dist.all_gather_into_tensor(ref, probe)
-            torch.cuda.synchronize(device)
-            self.ok = bool(torch.equal(got, ref))
-        except Exception as e:  # noqa: BLE001 - any failure means "use torch.distributed"
-            import sys
-            print(f"[fspann] direct RCCL disabled: {e}", file=sys.stderr)
-            self.ok = False
+            if device != "cpu":
+                torch.cuda.synchronize(device)
+            rc = L.fspann_allgather_topk_dev(self._h, nq, k, probe.data_ptr(), got.data_ptr())
+            ctx.sync()
+            dist.all_gather_into_tensor(ref, probe, group=group)       # every rank takes this one whatever rc was
+            if device != "cpu":
+                torch.cuda.synchronize(device)
+            if not agree(rc == 0 and bool(torch.equal(got, ref))):
+                self.close()
+                return note("verification exchange differs from all_gather_into_tensor")
+            lib = C.c_char_p()
+            L.fspann_comm_info(self._h, None, None, C.byref(lib))
+            self.library = (lib.value or b"").decode()
+            self.ok = True
+        except Exception as e:  # noqa: BLE001 - a Python-side failure here is not agreed on: report it loudly
+            self.close()
+            raise RuntimeError(f"fspann LibComm bootstrap failed on rank {rank}: {e}") from e
 
-    def allgather_bytes(self, send, recv, stream):
-        """ncclAllGather(send -> recv) of uint8 tensors on `stream` (a torch.cuda.Stream)."""
-        rc = self.lib.ncclAllGather(send.data_ptr(), recv.data_ptr(), send.numel(), 0, self.comm, stream.cuda_stream)  # 0 = ncclInt8
-        if rc != 0:
-            raise RuntimeError(f"ncclAllGather -> {rc}")
-
-    def allgather_topk(self, local: TopkBuffer, out: GatheredTopk, stream):
-        self.allgather_bytes(local.raw, out.raw, stream)
+    def allgather_topk(self, local: "TopkBuffer", out: "GatheredTopk"):
+        """Enqueued on the context's stream (behind the Refine that filled `local`)."""
+        from . import _native as N
+        N.check(self._L.fspann_allgather_topk_dev(self._h, local.q, local.k, local.raw.data_ptr(), out.raw.data_ptr()))
         return out
 
     def close(self):
-        if getattr(self, "comm", None) is not None and self.comm.value:
-            try:
-                self.lib.ncclCommDestroy(self.comm)
-            except Exception:  # noqa: BLE001
-                pass
-            self.comm = None
+        if self._h is not None:
+            self._L.fspann_comm_destroy(self._h)
+            self._h = None
+        self.ok = False
 
 
 class DeviceEvent:

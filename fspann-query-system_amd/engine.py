@@ -268,6 +268,16 @@ class FspannContext:
         N.check(self.L.fspann_store_set(self._h, v.shape[0], _p(v), _dt(v)))
         self.store_dtype = v.dtype
 
+    def store_attach_dev(self, n, ptr, dtype):
+        """Use caller-owned device rows [n][dim] as the store (no copy; keep them alive)."""
+        N.check(self.L.fspann_store_attach_dev(self._h, int(n), ptr, dtype))
+
+    def hbm_read_peak(self, nbytes=1 << 32, reps=5) -> float:
+        """GB/s of a pure-load kernel over `nbytes` of HBM on this device (bench.py roofline.peak_measured)."""
+        v = C.c_double(0.0)
+        N.check(self.L.fspann_hbm_read_peak(self._h, int(nbytes), int(reps), C.byref(v)))
+        return float(v.value)
+
     # -- device-pointer entry points (ints) ----------------------------------------------
     def encode_dev(self, nq, q_ptr, dtype, codes_ptr, hashes_ptr=0, bad_ptr=0):
         N.check(self.L.fspann_encode_dev(self._h, nq, q_ptr, dtype, codes_ptr, hashes_ptr or None, bad_ptr or None))

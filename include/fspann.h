@@ -201,6 +201,9 @@ int fspann_refine_timing_end(fspann_ctx* ctx, int* launches, double* total_ms);
  * crypto/AesGcmCryptoService.java:126-166), which stay on the host in production: keeps
  * plaintext rows in HBM and packs F_q rows into the [nq][B][dim] buffer Refine consumes.   */
 int fspann_store_set(fspann_ctx* ctx, int64_t n, const void* vectors, int dtype /* stored as given */);
+/* The same over rows that already live in HBM (caller-owned, 16-byte aligned, [n][dim]): no copy; the caller keeps
+ * them alive and unchanged until the next store_set / store_attach_dev / ctx_destroy.                        */
+int fspann_store_attach_dev(fspann_ctx* ctx, int64_t n, const void* vectors_dev, int dtype);
 int fspann_store_gather_dev(fspann_ctx* ctx, int64_t nq, const int32_t* sel_ids_dev, const int32_t* sel_count_dev,
                             int64_t B, void* cand_dev /* [nq][B][dim], store dtype */);
 /* Refine with the candidate rows read from the resident store by id (row j of query q =
@@ -221,6 +224,31 @@ int fspann_search_store_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int 
                             int k, int32_t* out_ids_dev, double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev,
                             int32_t* sel_ids_dev, int32_t* sel_count_dev, int32_t* bad_dev);
 const void* fspann_store_dev_ptr(fspann_ctx* ctx, int* dtype);
+
+/* ---- multi-GPU merge ---------------------------------------------------------
+ * The reference is a single JVM with a serial query loop (ForwardSecureANNSystem.java:636): it has no collective.  Here
+ * queries shard over GPUs (one context per GPU, index replicated, contiguous equal shards of the batch) and the ONLY
+ * exchange is one RCCL all-gather of every rank's packed top-k, enqueued on the context's stream behind Refine.
+ *   packed top-k of nq queries = [nq*k] int32 ids, padded to 8 bytes, then [nq*k] fp64 distances: hand
+ *   fspann_refine*_dev `base` as out_ids and `base + fspann_topk_dist_offset()` as out_dist and no packing is needed.
+ * Bootstrap: rank 0 calls fspann_comm_unique_id and ships the 128 bytes to the other ranks over the caller's own
+ * transport; every rank then calls fspann_comm_create (collective: blocks until all `world` ranks have called).
+ * librccl is bound at run time: $FSPANN_RCCL_LIB, an instance already in the process, else librccl.so.1.          */
+typedef struct fspann_comm fspann_comm;
+#define FSPANN_UNIQUE_ID_BYTES 128
+size_t fspann_topk_bytes(int64_t nq, int k);
+size_t fspann_topk_dist_offset(int64_t nq, int k);
+int fspann_comm_available(void);   /* 1 if librccl could be bound in this process (lets all ranks agree before the collective create) */
+int fspann_comm_unique_id(void* id_out /* FSPANN_UNIQUE_ID_BYTES */);
+int fspann_comm_create(fspann_ctx* ctx, const void* unique_id, int world, int rank, fspann_comm** out);
+int fspann_comm_destroy(fspann_comm* comm);
+int fspann_comm_info(fspann_comm* comm, int* world, int* rank, const char** library);
+/* gathered_dev = world * fspann_topk_bytes(nq_local, k) bytes, rank r's block at r * fspann_topk_bytes(). */
+int fspann_allgather_topk_dev(fspann_comm* comm, int64_t nq_local, int k, const void* local_packed_dev, void* gathered_dev);
+
+/* Measurement aid (bench.py roofline.peak_measured): GB/s at which this device streams `bytes` of HBM through a pure
+ * 16-byte-load kernel (best of `reps`); pick bytes well above the 256 MiB Infinity Cache.                         */
+int fspann_hbm_read_peak(fspann_ctx* ctx, size_t bytes, int reps, double* gb_per_s);
 
 /* ---- device memory helpers (so non-torch callers can own HBM buffers) ------------------- */
 int fspann_dev_alloc(fspann_ctx* ctx, size_t bytes, void** out);

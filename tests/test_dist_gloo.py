@@ -71,3 +71,36 @@ def test_shard_bounds():
     assert fd.shard_bounds(0, 2, 1) == (0, 0)
     with pytest.raises(ValueError):
         fd.shard_bounds(10, 2, 2)
+
+
+def _agree_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        graft.load_package()
+        from fspann_amd import dist as fd
+
+        class NoGpuCtx:                      # no device here: fspann_comm_create fails at once on every rank (null context)
+            handle = None
+
+            def sync(self):
+                pass
+
+        comm = fd.LibComm(NoGpuCtx(), world, rank, "cpu")
+        # every rank left the bootstrap the same way: the next collective of the group still pairs up
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)
+        ret[rank] = (comm.ok, int(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_libcomm_bootstrap_failure_is_agreed_on_by_all_ranks():
+    """A rank that cannot create its communicator must not leave its peers inside a collective: the bootstrap agrees on
+    every step over the existing group, all ranks fall back together (DirectRccl skipped the reference gather)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_agree_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: (False, 3), 1: (False, 3)}
