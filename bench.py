@@ -124,6 +124,10 @@ def main():
                     help="weak: --batch queries per GPU per step; strong: ONE batch of the workload's size cut into contiguous shards")
     ap.add_argument("--merge", default="inline", choices=["inline", "off"], help="N > 1: all-gather of the top-k behind Refine, same stream")
     ap.add_argument("--route-counters", action="store_true", help="also produce lastCandKept / rawSeen (forces the full select)")
+    ap.add_argument("--pipeline", default="serial", choices=["tick", "serial"],
+                    help="tick (value): three batches in flight, one launch per step = encode of batch t+2, Route of batch t+1 and "
+                         "Refine of batch t as ONE kernel (fspann_tick_dev); every step still does one encode, one Route and one "
+                         "Refine of a full batch.  serial: the three stages of ONE batch as three kernels, one after the other")
     args = ap.parse_args()
 
     # Only the final JSON line may reach stdout: libraries (RCCL prints a version banner) write to fd 1 too.
@@ -211,7 +215,12 @@ def main():
                     # packed (ids | distances) results, double-buffered; the merge is a single collective on them
                     topk=[fdist.TopkBuffer(Q, k, dev) for _ in range(2)],
                     out_cnt=torch.zeros(Q, dtype=torch.int32, device=dev), scored=torch.zeros(Q, dtype=torch.int32, device=dev),
-                    gathered=[fdist.GatheredTopk(world, Q, k, dev) for _ in range(2)] if use_dist else None, nsteps=0)
+                    gathered=[fdist.GatheredTopk(world, Q, k, dev) for _ in range(2)] if use_dist else None, nsteps=0,
+                    # tick pipeline: three batches in flight, each with its codes, F_q and the hand-over buffer of its Route
+                    slot=[dict(codes=torch.zeros((Q, TD, W), dtype=torch.int64, device=dev), bad=torch.zeros(Q, dtype=torch.int32, device=dev),
+                               sel_ids=torch.full((Q, B), -1, dtype=torch.int32, device=dev), sel_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
+                               hov=torch.zeros(max(1, ctx.route_handover_bytes(Q, probe_passes[-1])), dtype=torch.uint8, device=dev))
+                          for _ in range(3)], tick_no=0)
 
     bufs = [mkbufs() for _ in ctxs]
     streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
@@ -304,6 +313,68 @@ def main():
             events[4].record(stream)
         merge(b, par, stream)
 
+    def tick(mode, unfused=False):
+        """One step of the 3-deep pipeline on context 0: encode(batch t+2), Route(batch t+1), Refine(batch t) — ONE launch.
+        unfused: the same three operations as three stand-alone launches (used for the few steps of the timed region whose
+        refinement-scan dispatch carries the kernel-attached events the roofline is read from)."""
+        cx, stream, b = ctxs[0], streams[0], bufs[0]
+        t = b["tick_no"]
+        b["tick_no"] += 1
+        bE, bR, bF = (t + 2) % NB, (t + 1) % NB, t % NB
+        sE, sR, sF = b["slot"][(t + 2) % 3], b["slot"][(t + 1) % 3], b["slot"][t % 3]
+        par = t & 1
+        tk = b["topk"][par]
+        pov = probe_passes[-1]
+        if unfused:
+            cx.refine_dev(Q, q_all[bF].data_ptr(), F32, cand_all[bF].data_ptr(), F32, B, sF["sel_ids"].data_ptr(), sF["sel_cnt"].data_ptr(), k,
+                          tk.ids.data_ptr(), tk.dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr()) if mode == "dense" else \
+                cx.refine_store_dev(Q, q_all[bF].data_ptr(), F32, B, sF["sel_ids"].data_ptr(), sF["sel_cnt"].data_ptr(), k, tk.ids.data_ptr(),
+                                    tk.dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
+            cx.route_dev(Q, sR["codes"].data_ptr(), pov, B, B, sR["sel_ids"].data_ptr(), 0, sR["sel_cnt"].data_ptr(), 0, 0)
+            cx.encode_dev(Q, q_all[bE].data_ptr(), F32, sE["codes"].data_ptr(), 0, sE["bad"].data_ptr())
+        else:
+            cx.tick_dev(
+                encode=dict(nq=Q, q=q_all[bE].data_ptr(), codes=sE["codes"].data_ptr(), bad=sE["bad"].data_ptr()),
+                route=dict(nq=Q, codes=sR["codes"].data_ptr(), limit=B, probe_override=pov, ids=sR["sel_ids"].data_ptr(),
+                           count=sR["sel_cnt"].data_ptr(), handover=sR["hov"].data_ptr()),
+                refine=dict(nq=Q, q=q_all[bF].data_ptr(), B=B, ids=sF["sel_ids"].data_ptr(), count=sF["sel_cnt"].data_ptr(), k=k,
+                            cand=cand_all[bF].data_ptr() if mode == "dense" else None, codes=sF["codes"].data_ptr(), handover=sF["hov"].data_ptr(),
+                            probe_override=pov, out_ids=tk.ids.data_ptr(), out_dist=tk.dist.data_ptr(), out_count=b["out_cnt"].data_ptr(),
+                            scored=b["scored"].data_ptr()))
+        merge(b, par, stream)
+
+    def tick_prime():
+        """fill the pipeline (untimed): encode of batches 0 and 1, Route of batch 0"""
+        cx, b = ctxs[0], bufs[0]
+        b["tick_no"] = 0
+        s0, s1 = b["slot"][0], b["slot"][1]
+        cx.encode_dev(Q, q_all[0].data_ptr(), F32, s0["codes"].data_ptr(), 0, s0["bad"].data_ptr())
+        cx.route_dev(Q, s0["codes"].data_ptr(), probe_passes[-1], B, B, s0["sel_ids"].data_ptr(), 0, s0["sel_cnt"].data_ptr(), 0, 0)
+        cx.encode_dev(Q, q_all[1 % NB].data_ptr(), F32, s1["codes"].data_ptr(), 0, s1["bad"].data_ptr())
+
+    def timed_tick(mode, steps, warmup, with_events=False):
+        tick_prime()
+        for _ in range(warmup):
+            tick(mode)
+        barrier()
+        every = max(2, steps // 8)
+        if with_events:
+            ctxs[0].refine_timing_begin(steps, 1)          # only the unfused steps launch a refinement scan of their own
+        t_s = time.perf_counter()
+        for i in range(steps):
+            tick(mode, unfused=with_events and (i % every) == every - 1)
+        ctxs[0].sync()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t_s
+        if use_dist:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        rt = [ctxs[0].refine_timing_end()] if with_events else None
+        return el, rt, every
+
     def barrier():
         for c_ in ctxs:
             c_.sync()
@@ -341,7 +412,13 @@ def main():
 
     # ---------------- the timed region ------------------------------------------------------------------------------------
     mode = args.candidates
-    elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, with_events=True)
+    use_tick = args.pipeline == "tick" and mode in ("dense", "store") and len(probe_passes) == 1 and not args.route_counters
+    if use_tick:
+        elapsed, rt, TIMED_EVERY = timed_tick(mode, args.steps, args.warmup, with_events=True)
+        tick_fused = ctx.last_tick_fused()
+    else:
+        elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, with_events=True)
+        tick_fused = False
     ref_launches = sum(x for x, _ in rt)
     ref_ms = sum(t for _, t in rt) / max(1, ref_launches)          # kernel-attached HIP events, on the context's stream
     ms_per_step = elapsed * 1000.0 / args.steps
@@ -361,11 +438,22 @@ def main():
     # ---------------- extra passes (N = 1; reported beside `value`, never as it) -------------------------------------------
     variants, pipelined, hbm_proof, cfg4_shape, peak_measured = {}, None, None, None, None
     if extras:
+        if use_tick:
+            el_s, _, _ = timed(mode, args.steps, max(2, args.warmup))
+            variants["serial"] = dict(value=round(Q * args.steps / el_s, 1), unit="queries/s", ms_per_step=round(el_s * 1000.0 / args.steps, 4),
+                                      note="the three stages of ONE batch as three kernels one after the other (encode, Route, Refine): latency of a "
+                                           "single batch; nothing overlaps")
+            other = "store" if mode == "dense" else "dense"
+            el_o, _, _ = timed_tick(other, args.steps, max(2, args.warmup))
+            variants["tick_" + other] = dict(value=round(Q * args.steps / el_o, 1), unit="queries/s", ms_per_step=round(el_o * 1000.0 / args.steps, 4),
+                                             note=("trusted-HBM variant of the same pipeline: Refine reads plaintext rows of an HBM-resident store by id; "
+                                                   "production keeps decrypt on the host, so this is NOT the reference's boundary") if other == "store"
+                                             else "the same pipeline over resident [Q][B][d] blocks (SURVEY 8d kernel path)")
         for vm, note in (("store", "trusted-HBM variant: Refine reads plaintext rows of an HBM-resident store by id (one library call per step); "
                                    "production keeps decrypt on the host, so this is NOT the reference's boundary"),
                          ("gather", "the [Q][B][d] block is packed inside the step by a gather kernel (device stand-in for load + decrypt), then scanned"),
                          ("dense", "the [Q][B][d] block is resident before the step (SURVEY 8d kernel path)")):
-            if vm == mode:
+            if vm == mode and not use_tick:
                 continue
             el_v, _, _ = timed(vm, args.steps, max(2, args.warmup))
             variants[vm] = dict(value=round(Q * args.steps / el_v, 1), unit="queries/s", ms_per_step=round(el_v * 1000.0 / args.steps, 4), note=note)
@@ -381,7 +469,11 @@ def main():
         b_["nsteps"] = 0
     step_no[0] = 0
     barrier()
-    step(mode, batch=0)
+    if use_tick:       # batch 0 is refined by tick 0 (its encode and Route were done by tick_prime)
+        tick_prime()
+        tick(mode)
+    else:
+        step(mode, batch=0)
     barrier()
     out_ids, out_dist = bufs[0]["topk"][0].ids, bufs[0]["topk"][0].dist
     got_ids, got_dist = out_ids.cpu().numpy(), out_dist.cpu().numpy()
@@ -471,8 +563,10 @@ def main():
                     traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5), launches=ref_launches,
                     working_set_bytes=(NB * Q * B * d * 4) if mode == "dense" else n * d * 4,
-                    timing="HIP start/stop events attached to every %d-th refine_scan_kernel dispatch of the timed region "
-                           "(hipExtLaunchKernel, on the context's stream)" % TIMED_EVERY,
+                    timing=("every %d-th step of the timed region runs its three stages as stand-alone kernels instead of the shared one; the "
+                            "refine_scan_kernel dispatch of those steps carries HIP start/stop events (hipExtLaunchKernel, on the context's stream)"
+                            if use_tick else "HIP start/stop events attached to every %d-th refine_scan_kernel dispatch of the timed region "
+                            "(hipExtLaunchKernel, on the context's stream)") % TIMED_EVERY,
                     bracket_ms=round(float(st_mean[3]), 5), hbm_proof=hbm_proof, cfg4_shape=cfg4_shape)
 
     # Route (probe + select) is bound by dependent L2 rounds and LDS atomics, not by HBM or MFMA; its algorithmic bytes
@@ -589,6 +683,9 @@ def main():
                        "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "queries_per_step": q_job,
                        "distinct_query_batches": NB, "route_counters": bool(args.route_counters), "passes_per_step": len(probe_passes),
                        "parallelism": f"query-sharded x{world}, index replicated", "merge": gather_path, "streams_per_gpu": 1,
+                       "pipeline": ("tick: 3 batches in flight, one launch per step = encode(t+2) + Route(t+1) + Refine(t) as one kernel (tick_kernel, "
+                                    "fused=%s); every step does one full-batch encode, Route and Refine" % tick_fused) if use_tick
+                       else "serial: encode, Route, Refine of one batch as three kernels",
                        "candidates": {"dense": "kernel path (SURVEY 8d): [Q][B][d] blocks of decrypted candidate rows resident in HBM before the timed "
                                                "region (packed once per distinct batch), scanned by refine_scan_kernel",
                                       "store": "trusted-HBM variant: rows read from an HBM-resident plaintext store by id inside the refine scan",

@@ -60,6 +60,19 @@ class Cfg(C.Structure):
         "max_global_candidates", "refinement_limit", "hamming_prefilter_threshold", "reserved")]
 
 
+class Tick(C.Structure):
+    """fspann_tick of include/fspann.h (device pointers as integers; 0 / None = absent)."""
+    _fields_ = [
+        ("nq_encode", C.c_int64), ("enc_q_dev", C.c_void_p), ("enc_dtype", C.c_int32), ("pad0", C.c_int32),
+        ("enc_codes_dev", C.c_void_p), ("enc_bad_dev", C.c_void_p),
+        ("nq_route", C.c_int64), ("route_codes_dev", C.c_void_p), ("route_probe_override", C.c_int32), ("route_limit", C.c_int32),
+        ("route_ids_dev", C.c_void_p), ("route_count_dev", C.c_void_p), ("route_handover_dev", C.c_void_p),
+        ("nq_refine", C.c_int64), ("ref_q_dev", C.c_void_p), ("ref_q_dtype", C.c_int32), ("ref_cand_dtype", C.c_int32),
+        ("ref_cand_dev", C.c_void_p), ("ref_B", C.c_int64), ("ref_ids_dev", C.c_void_p), ("ref_count_dev", C.c_void_p),
+        ("ref_codes_dev", C.c_void_p), ("ref_handover_dev", C.c_void_p), ("ref_probe_override", C.c_int32), ("k", C.c_int32),
+        ("out_ids_dev", C.c_void_p), ("out_dist_dev", C.c_void_p), ("out_count_dev", C.c_void_p), ("scored_dev", C.c_void_p)]
+
+
 def sources():
     return [os.path.join(_SRC, f) for f in sorted(os.listdir(_SRC))]
 
@@ -73,9 +86,11 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc cross-compiles for gfx950 without a GPU present."""
+    """hipcc cross-compiles for gfx950 without a GPU present.  FSPANN_BUILD_DEBUG=1: with the per-phase clock stamps and
+    the fspann_debug_route_stamps export the tools/ scripts use (never part of a release build)."""
     if force or needs_build():
-        cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", _SO, os.path.join(_SRC, "fspann_api.hip")]
+        dbg = ["-DFSPANN_DEBUG_STAMPS"] if os.environ.get("FSPANN_BUILD_DEBUG") == "1" else []
+        cmd = ["hipcc"] + HIPCC_FLAGS + dbg + ["-o", _SO, os.path.join(_SRC, "fspann_api.hip")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -125,6 +140,9 @@ _SIGS = {
     "fspann_store_attach_dev": (_i, [_vp, _i64, _vp, _i]),
     "fspann_store_gather_dev": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "fspann_store_dev_ptr": (_vp, [_vp, C.POINTER(_i)]),
+    "fspann_route_handover_bytes": (_sz, [_vp, _i64, _i]),
+    "fspann_tick_dev": (_i, [_vp, C.POINTER(Tick)]),
+    "fspann_last_tick_fused": (_i, [_vp]),
     "fspann_topk_bytes": (_sz, [_i64, _i]),
     "fspann_topk_dist_offset": (_sz, [_i64, _i]),
     "fspann_comm_available": (_i, []),

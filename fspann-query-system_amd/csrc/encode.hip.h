@@ -27,26 +27,50 @@ __device__ __forceinline__ int32_t java_d2i(double x) {
     return static_cast<int32_t>(x);
 }
 
+// Arguments of one exact-coding launch (or of the encode role of tick_kernel).
+template <typename TIn>
+struct EncodeArgs {
+    const TIn* q;
+    int64_t nq;
+    int d;
+    const double* alphaT;
+    const double* r;
+    const double* omega;
+    int P, m, lambda, W, TD, tdPerBlock;
+    uint64_t* codes;
+    int32_t* hashes;
+    int32_t* bad;
+    double* proj;
+    const unsigned long long* only_if_over;   // fallback launch behind the MFMA path: runs only when its re-check list overflowed
+    unsigned long long over_cap;
+};
+
+// One workgroup (kEncThreads threads): QB query vectors x tdPerBlock tables; block (bx, by) of ceil(nq / QB) x ceil(TD / tdPerBlock).
+// lds = (QB * kEncThreads + QB) int32 of LDS scratch (static in encode_exact_kernel, part of the dynamic LDS in tick_kernel).
 template <typename TIn, int QB>
-__global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
-    const TIn* __restrict__ q, int64_t nq, int d, const double* __restrict__ alphaT,
-    const double* __restrict__ r, const double* __restrict__ omega, int P, int m, int lambda, int W, int TD,
-    int tdPerBlock, uint64_t* __restrict__ codes, int32_t* __restrict__ hashes, int32_t* __restrict__ bad,
-    double* __restrict__ proj, const unsigned long long* __restrict__ only_if_over, unsigned long long over_cap) {
-    // fallback launch behind the MFMA path: runs only when its re-check list overflowed
-    if (only_if_over && *only_if_over <= over_cap) return;
-    __shared__ int32_t Hs[QB * kEncThreads];
-    __shared__ int badq[QB];
+__device__ __forceinline__ void encode_exact_block(const EncodeArgs<TIn>& a, const int bx, const int by, int32_t* lds) {
+    const TIn* __restrict__ q = a.q;
+    const int64_t nq = a.nq;
+    const int d = a.d, P = a.P, m = a.m, lambda = a.lambda, W = a.W, TD = a.TD, tdPerBlock = a.tdPerBlock;
+    const double* __restrict__ alphaT = a.alphaT;
+    const double* __restrict__ r = a.r;
+    const double* __restrict__ omega = a.omega;
+    uint64_t* __restrict__ codes = a.codes;
+    int32_t* __restrict__ hashes = a.hashes;
+    int32_t* __restrict__ bad = a.bad;
+    double* __restrict__ proj = a.proj;
+    if (a.only_if_over && *a.only_if_over <= a.over_cap) return;
+    int32_t* Hs = lds;                       // [QB * kEncThreads]
+    int* badq = lds + QB * kEncThreads;      // [QB]
 
     const int tid = threadIdx.x;
-    const int64_t q0 = static_cast<int64_t>(blockIdx.x) * QB;
-    const int td0 = blockIdx.y * tdPerBlock;
+    const int64_t q0 = static_cast<int64_t>(bx) * QB;
+    const int td0 = by * tdPerBlock;
     const int tdn = min(tdPerBlock, TD - td0);
     const int nproj = tdn * m;
     const bool active = tid < nproj;
     const int p = td0 * m + tid;
 
-    if (tid < QB) badq[tid] = 0;
     // NaN / Inf in a query vector (Coding.java:356-361): every thread fetches its share of the QB rows NOW and looks at it
     // after the projection loop, so this round trip is hidden behind the loop (the sums simply carry a NaN)
     constexpr int kChk = 4;                       // elements per thread kept in registers; longer rows are checked in place
@@ -65,22 +89,55 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
     // The query elements are the same for every lane (one lane = one projection): their addresses are wave-uniform,
     // so they come through the scalar cache (s_load) and feed the fp64 multiply as scalar operands — no LDS staging,
     // no barrier in the loop.  alpha is streamed coalesced from alphaT (64 consecutive doubles per wave and dimension).
-    const TIn* qrow[QB];
+    // The rows are read through the CONSTANT address space: a uniform load from it is always a scalar load.  (Through the
+    // plain global pointer the compiler must first prove that nothing in the kernel can write the row; it can in
+    // encode_exact_kernel, it cannot once this function is one role of tick_kernel — the loads then become vector loads, each
+    // alpha load waits for them, and a workgroup takes 41 us instead of 12.)  The query batch is an input: nothing writes it.
+    typedef const TIn __attribute__((address_space(4)))* const_row_t;
+    const_row_t qrow[QB];
 #pragma unroll
-    for (int qq = 0; qq < QB; qq++) qrow[qq] = q + min(q0 + qq, nq - 1) * d;   // rows past nq: computed, never stored
+    for (int qq = 0; qq < QB; qq++) qrow[qq] = (const_row_t)(q + min(q0 + qq, nq - 1) * d);   // rows past nq: computed, never stored
     if (active) {
+        // alpha_j is streamed eight dimensions at a time, the NEXT eight requested before the current eight are used, and a
+        // scheduling barrier keeps the compiler from sinking the loads to their uses (inside tick_kernel, whose route role
+        // sits at the register ceiling, it otherwise emits load / wait / load / wait: eight dependent round trips per block).
         const double* ap = alphaT + p;
-#pragma unroll 8
-        for (int i = 0; i < d; i++) {
-            const double a = ap[static_cast<int64_t>(i) * P];
+        constexpr int U = 8;
+        const int dU = d & ~(U - 1);               // whole blocks of eight dimensions (no guards inside: the query elements of a
+        if (dU > 0) {                              // block stay ONE 32-byte scalar load per query)
+            double cur[U], nxt[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) cur[u] = ap[static_cast<int64_t>(u) * P];
+            for (int i = 0; i < dU; i += U) {
+                const int inx = (i + U < dU) ? i + U : i;          // last block: re-request the current one (values unused)
+#pragma unroll
+                for (int u = 0; u < U; u++) nxt[u] = ap[static_cast<int64_t>(inx + u) * P];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+#pragma unroll
+                    for (int qq = 0; qq < QB; qq++) {
+                        const double prod = static_cast<double>(qrow[qq][i + u]) * cur[u];  // acc += a[i]*b[i], Coding.java:351
+                        acc[qq] = acc[qq] + prod;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) cur[u] = nxt[u];
+            }
+        }
+        for (int i = dU; i < d; i++) {
+            const double a1 = ap[static_cast<int64_t>(i) * P];
 #pragma unroll
             for (int qq = 0; qq < QB; qq++) {
-                const double prod = static_cast<double>(qrow[qq][i]) * a;  // acc += a[i]*b[i], Coding.java:351
+                const double prod = static_cast<double>(qrow[qq][i]) * a1;
                 acc[qq] = acc[qq] + prod;
             }
         }
     }
 
+    // (no LDS store ahead of the projection loop: with one, the loop's query loads stop being scalar loads and every
+    // alpha load waits for the previous one — measured 41 us per workgroup instead of 12 inside tick_kernel)
+    if (tid < QB) badq[tid] = 0;
     __syncthreads();                                  // badq[] is zero
 #pragma unroll
     for (int u = 0; u < kChk; u++) {
@@ -148,7 +205,13 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(
             codes[(qi * TD + td0 + tdl) * W + w] = word;
         }
     }
-    if (bad && blockIdx.y == 0 && tid < QB && q0 + tid < nq) bad[q0 + tid] = badq[tid];
+    if (bad && by == 0 && tid < QB && q0 + tid < nq) bad[q0 + tid] = badq[tid];
+}
+
+template <typename TIn, int QB>
+__global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(EncodeArgs<TIn> a) {
+    __shared__ int32_t lds[QB * kEncThreads + QB];
+    encode_exact_block<TIn, QB>(a, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), lds);
 }
 
 }  // namespace fspann

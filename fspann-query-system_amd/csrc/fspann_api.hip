@@ -14,6 +14,7 @@
 #include "refine.hip.h"
 #include "route.hip.h"
 #include "route_lazy.hip.h"
+#include "tick.hip.h"
 
 using namespace fspann;
 
@@ -229,20 +230,16 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
     }
     const int tdPerBlock = std::max(1, kEncThreads / m);
     const int gy = (c->TD + tdPerBlock - 1) / tdPerBlock;
-    // QB queries per block: 8 for bulk coding (index build), 2 for query batches so that
+    const EncodeArgs<TIn> ea{q_dev, nq, c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD, tdPerBlock,
+                             codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap};
+    // QB queries per block: 8 for bulk coding (index build), 4 for query batches so that
     // a 1024-query batch still fills 256 CUs.
     if (nq >= 8192) {
         constexpr int QB = 8;
-        dim3 grid(static_cast<unsigned>((nq + QB - 1) / QB), gy);
-        hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), grid, dim3(kEncThreads), 0, c->stream, q_dev, nq,
-                           c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD,
-                           tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap);
+        hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
     } else {
         constexpr int QB = 4;
-        dim3 grid(static_cast<unsigned>((nq + QB - 1) / QB), gy);
-        hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), grid, dim3(kEncThreads), 0, c->stream, q_dev, nq,
-                           c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD,
-                           tdPerBlock, codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap);
+        hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
     }
     FSP_HIP(hipGetLastError());
     return FSPANN_OK;
@@ -256,7 +253,7 @@ struct RoutePlan {
     int64_t g_sort_stride;
     // bounded select (route_lazy.hip.h)
     int lazy, lazy_cap, lz_ht_size, lz_grid;
-    size_t lz_lds_bytes;
+    size_t lz_lds_bytes, small_bytes;
 };
 
 int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, RoutePlan& pl, bool want_counters = true) {
@@ -284,6 +281,7 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
         return static_cast<size_t>(sort_cap) * 8 + static_cast<size_t>(pl.ht_size) * 4 + static_cast<size_t>(pl.max_tuples) * 4 +
                ((static_cast<size_t>(pl.max_tuples) * 2 + 15) & ~size_t(15));
     };
+    pl.small_bytes = small;
     const size_t budget = static_cast<size_t>(c->lds_limit) - 1024;  // static __shared__ + margin
     if (small + 8192 > budget) return fail(FSPANN_E_RANGE, "route: T*D*probes = %zu probe slots do not fit in LDS", TP);
     pl.arena_bytes = (arena(pl.sort_cap) + 255) & ~size_t(255);
@@ -305,7 +303,7 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
         const int cap_env = c->knob_lazy_cap;   // tests: distinct ids one query may hold before it is handed back
         const size_t lds = static_cast<size_t>(kLzHtSize) * 8 + TP * 16 + 4096 + 4096 + (TP + 2) * 8 + (TP + 1) * 4 + 8 +
                            static_cast<size_t>(c->TD) * 8 + ((TP * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kLzEntries) * 2 + 4096 + static_cast<size_t>(c->TD) * 4 + 16;
-        if (TP < 32768 && lds <= budget) {
+        if (TP < 32768 && lds <= budget && small <= lds) {   // small <= lds: a handed-over query runs the full select over this LDS
             pl.lazy = 1;
             pl.lazy_cap = (cap_env > 0) ? std::min(cap_env, kLzEntries) : kLzEntries;
             pl.lz_ht_size = kLzHtSize;
@@ -337,28 +335,35 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     const bool vec = (d % VN == 0) && ((reinterpret_cast<uintptr_t>(cand) & 15) == 0);
     const size_t lds = std::max<size_t>(static_cast<size_t>(kRefRows) * (vec ? DC + VN : DC + 1) * sizeof(TC), static_cast<size_t>(kRefRows) * 16);
     const unsigned grid = static_cast<unsigned>(nq * nchunks);
-    const int64_t store_n = GATHER ? c->store_n : 0;
-    if (vec) {
-        auto kern = refine_scan_kernel<TC, TQ, DC, true, GATHER>;
+    const RefineArgs<TC, TQ> ra{q, cand, GATHER ? c->store_n : 0, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt};
+    auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {   // start/stop events attached to this very dispatch
-            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, c->rt_events[c->rt_used], c->rt_events[c->rt_used + 1], 0,
-                                  q, cand, store_n, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, c->rt_events[c->rt_used], c->rt_events[c->rt_used + 1], 0, ra);
             c->rt_used += 2;
-        } else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, store_n, B, d, cand_ids, cand_count, k,
-                           nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
-    } else {
-        auto kern = refine_scan_kernel<TC, TQ, DC, false, GATHER>;
-        if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {   // start/stop events attached to this very dispatch
-            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, c->rt_events[c->rt_used], c->rt_events[c->rt_used + 1], 0,
-                                  q, cand, store_n, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
+        } else {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, ra);
+        }
+        return FSPANN_OK;
+    };
+    int lrc = FSPANN_OK;
+    bool streamed = false;
+    if constexpr (DC * sizeof(TC) == 128) if (vec && c->knob_refine_stream > 0) {
+        // the scan as a stream: knob_refine_stream workgroups per CU, each walking several (query, chunk) units with the loads
+        // of the next two tiles in flight across unit boundaries (refine_stream_run)
+        const int64_t units = nq * nchunks;
+        const unsigned sgrid = static_cast<unsigned>(std::min<int64_t>(units, static_cast<int64_t>(c->num_cus) * c->knob_refine_stream));
+        auto kern = refine_stream_kernel<TC, TQ, DC, GATHER>;
+        if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {
+            hipExtLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, c->rt_events[c->rt_used], c->rt_events[c->rt_used + 1], 0, ra, nq);
             c->rt_used += 2;
-        } else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kRefRows), lds, c->stream, q, cand, store_n, B, d, cand_ids, cand_count, k,
-                           nchunks, out_ids, out_dist, out_count, scored, partial, pcnt);
+        } else {
+            hipLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, ra, nq);
+        }
+        streamed = true;
     }
+    if (!streamed) lrc = vec ? launch(refine_scan_kernel<TC, TQ, DC, true, GATHER>) : launch(refine_scan_kernel<TC, TQ, DC, false, GATHER>);
+    if (lrc) return lrc;
     FSP_HIP(hipGetLastError());
     if (nchunks > 1) {
         hipLaunchKernelGGL(refine_merge_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), 0, c->stream, partial, pcnt,
@@ -465,6 +470,10 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_lazy_cap = std::max(0, env_int("FSPANN_ROUTE_LAZY_CAP", 0));
         c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
+        c->knob_refine_stream = std::min(4, std::max(0, env_int("FSPANN_REFINE_STREAM", 2)));
+        c->knob_tick_refine = std::min(4, std::max(1, env_int("FSPANN_TICK_REFINE", 1)));
+        c->knob_tick_fuse = env_int("FSPANN_TICK_FUSE", 1) != 0;
+        c->knob_tick_front = std::min(100, std::max(0, env_int("FSPANN_TICK_FRONT", 50)));
     }
     c->h_min.resize(c->TD); c->h_max.resize(c->TD); c->h_off.resize(c->TD); c->h_rep.resize(c->TD); c->h_ids.resize(c->TD);
     c->h_table_set.assign(c->TD, 0);
@@ -484,6 +493,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits); free_devt(c->d_unmodelled);
     if (c->store_owned) free_dev(c->d_store);
+    free_dev(c->ws_tickfix.p); free_dev(c->d_fixparams);
     free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
@@ -871,13 +881,16 @@ int64_t fspann_route_max_candidates(fspann_ctx* c, int probe_override) {
     return std::min<int64_t>(mt, static_cast<int64_t>(c->hard_cap) - 1 + c->cfg.block_size);
 }
 
-int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit,
-                     int64_t cap, int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev,
-                     int32_t* raw_seen_dev) {
-    CHECK_CTX(c);
+}  // extern "C"
+
+namespace {
+
+// Argument checks + plan + kernel parameters of one Route call (shared by fspann_route_dev and fspann_tick_dev).
+int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit, int64_t cap, int32_t* ids_dev,
+                  int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev, int32_t* raw_seen_dev, RoutePlan* plan_out, RouteParams* prm_out,
+                  bool* fused_out) {
     if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");  // PIS:594
     if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
-    if (nq == 0) return FSPANN_OK;
     if (!codes_dev) return fail(FSPANN_E_STATE, "MSANNP violation: QueryToken missing BitSet codes");  // PIS:602
     if (!ids_dev || !count_dev) return fail(FSPANN_E_NULL, "output buffer is null");
     if (limit <= 0) return fail(FSPANN_E_ARG, "limit must be > 0");
@@ -886,9 +899,10 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     if (rc) return rc;
     const int64_t need = std::min<int64_t>(limit, pl.maxcand);
     if (cap < need) return fail(FSPANN_E_RANGE, "cap %lld < min(limit, worst case) = %lld", (long long)cap, (long long)need);
+    // global arenas of the full select: per-workgroup scratch when it does not fit LDS, the sort buffer of long lists
     const size_t ar_g = pl.lds_mode ? 0 : static_cast<size_t>(pl.grid) * pl.arena_bytes;
     const size_t so_g = static_cast<size_t>(pl.grid) * pl.g_sort_stride * 8;
-    if (ar_g + so_g && (rc = ensure(c, c->ws_route, ar_g + so_g + 256))) return rc;
+    if (ar_g + so_g && (rc = ensure(c, c->ws_route, ar_g + so_g + 512))) return rc;
     RouteParams p{};
     p.codes = codes_dev; p.tables = c->d_tables; p.keys2 = c->d_keys2; p.rep = c->d_rep; p.id_off = c->d_off; p.ids = c->d_ids;
     p.java_hash = c->d_java_hash; p.deleted_bits = c->d_deleted_bits;
@@ -904,6 +918,12 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     p.unmodelled = c->d_unmodelled;
     p.decimal_ids = c->decimal_ids ? 1 : 0;
     p.out_cap = cap; p.out_ids = ids_dev; p.out_score = score_dev; p.out_count = count_dev; p.out_kept = kept_dev; p.out_raw = raw_seen_dev;
+    // probe lists in global memory: route_probe_kernel's output, and where the bounded select puts a query it hands over
+    const size_t TPn = static_cast<size_t>(c->TD) * pl.P;
+    const size_t probe_bytes = static_cast<size_t>(nq) * TPn * 16, np_bytes = static_cast<size_t>(nq) * c->TD * 4;
+    if ((rc = ensure(c, c->ws_probe, probe_bytes + np_bytes + 256))) return rc;
+    p.probe_g = static_cast<int4*>(c->ws_probe.p);
+    p.nprobe_g = reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_probe.p) + ((probe_bytes + 255) & ~size_t(255)));
     bool fused = false;
     if (pl.lazy) {
         if ((rc = ensure(c, c->ws_ovf, static_cast<size_t>(nq) * 4 + 256))) return rc;
@@ -921,22 +941,42 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
         fused = c->knob_fused_probe && (kLzThreads / 16) * (2 * pl.P - 1) * 12 <= 4096 && c->TD <= 512;
         p.probe_G = fused ? 16 : 0;
     }
-    // kernel 1: search + probe order, one lane group per (query, table)
-    const size_t TPn = static_cast<size_t>(c->TD) * pl.P;
-    const size_t probe_bytes = static_cast<size_t>(nq) * TPn * 16, np_bytes = static_cast<size_t>(nq) * c->TD * 4;
-    if ((rc = ensure(c, c->ws_probe, probe_bytes + np_bytes + 256))) return rc;
-    int4* probe_dev = static_cast<int4*>(c->ws_probe.p);
-    int32_t* nprobe_dev = reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_probe.p) + ((probe_bytes + 255) & ~size_t(255)));
-    if (!fused) {
-        int G = 64;
-        while (G > 2 && G / 2 >= 2 * pl.P - 1 && G / 2 >= 16) G >>= 1;  // >= 16 lanes per table: 3-4 search rounds
-        const int gpb = kProbeThreads / G;
-        const int64_t nitems = nq * c->TD;
-        const unsigned grid1 = static_cast<unsigned>((nitems + gpb - 1) / gpb);
-        const size_t lds1 = static_cast<size_t>(gpb) * (2 * pl.P - 1) * 12;
-        hipLaunchKernelGGL(route_probe_kernel, dim3(grid1), dim3(kProbeThreads), lds1, c->stream, p, probe_dev, nprobe_dev, G);
-        FSP_HIP(hipGetLastError());
-    }
+    *plan_out = pl;
+    *prm_out = p;
+    *fused_out = fused;
+    return FSPANN_OK;
+}
+
+// kernel 1 of the unfused route: search + probe order, one lane group per (query, table)
+int launch_route_probe(fspann_ctx* c, const RouteParams& p, const RoutePlan& pl) {
+    int G = 64;
+    while (G > 2 && G / 2 >= 2 * pl.P - 1 && G / 2 >= 16) G >>= 1;  // >= 16 lanes per table: 3-4 search rounds
+    const int gpb = kProbeThreads / G;
+    const int64_t nitems = p.nq * c->TD;
+    const unsigned grid1 = static_cast<unsigned>((nitems + gpb - 1) / gpb);
+    const size_t lds1 = static_cast<size_t>(gpb) * (2 * pl.P - 1) * 12;
+    hipLaunchKernelGGL(route_probe_kernel, dim3(grid1), dim3(kProbeThreads), lds1, c->stream, p, p.probe_g, p.nprobe_g, G);
+    FSP_HIP(hipGetLastError());
+    return FSPANN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit,
+                     int64_t cap, int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev,
+                     int32_t* raw_seen_dev) {
+    CHECK_CTX(c);
+    if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");  // PIS:594
+    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    if (nq == 0) return FSPANN_OK;
+    RoutePlan pl;
+    RouteParams p{};
+    bool fused = false;
+    int rc = prepare_route(c, nq, codes_dev, probe_override, limit, cap, ids_dev, score_dev, count_dev, kept_dev, raw_seen_dev, &pl, &p, &fused);
+    if (rc) return rc;
+    if (!fused && (rc = launch_route_probe(c, p, pl))) return rc;
 #define FSP_LAUNCH_SEL(LDS, THR)                                                                                         \
     do {                                                                                                                 \
         auto kern = route_select_kernel<LDS, THR>;                                                                       \
@@ -946,7 +986,7 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
                                         159 * 1024));                                                                    \
             c->attr_mask |= abit;                                                                                        \
         }                                                                                                                \
-        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(THR), pl.lds_bytes, c->stream, p, probe_dev, nprobe_dev);           \
+        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(THR), pl.lds_bytes, c->stream, p, p.probe_g, p.nprobe_g);           \
     } while (0)
     c->last_route_lazy = pl.lazy;
     if (pl.lazy) {
@@ -955,9 +995,9 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
             FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
             c->attr_mask |= 16u;
         }
-        hipLaunchKernelGGL(lk, dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p, probe_dev, nprobe_dev);
+        hipLaunchKernelGGL(lk, dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
         FSP_HIP(hipGetLastError());
-        // queries the bounded select handed back (none, normally): the full select over the overflow list
+        // queries the bounded select handed over (none, normally): the full select over the overflow list
         p.qcount = p.ovf_count; p.qlist = p.ovf_list;
         pl.grid = std::min(pl.grid, 32);    // normally nothing to do: keep the launch small
     }
@@ -1182,6 +1222,210 @@ int fspann_search_store_dev(fspann_ctx* c, int64_t nq, const void* q_dev, int q_
     if ((rc = fspann_encode_dev(c, nq, q_dev, q_dtype, codes, nullptr, bad))) return rc;
     if ((rc = fspann_route_dev(c, nq, codes, probe_override, static_cast<int32_t>(B), B, sel, nullptr, cnt, nullptr, nullptr))) return rc;
     return fspann_refine_store_dev(c, nq, q_dev, q_dtype, B, sel, cnt, k, out_ids_dev, out_dist_dev, out_count_dev, scored_dev);
+}
+
+// ---- one launch for encode / Route / Refine of three batches in flight (tick.hip.h) ---------------------------------------
+size_t fspann_route_handover_bytes(fspann_ctx* c, int64_t nq, int probe_override) {
+    if (!c || nq <= 0) return 0;
+    const size_t TP = static_cast<size_t>(c->TD) * effective_probes(c, probe_override);
+    return ((static_cast<size_t>(nq) * TP * 16 + 255) & ~size_t(255)) + static_cast<size_t>(nq) * c->TD * 4 + 256;
+}
+int fspann_last_tick_fused(fspann_ctx* c) { return c ? c->last_tick_fused : 0; }
+
+}  // extern "C"
+namespace {
+void handover_ptrs(fspann_ctx* c, void* buf, int64_t nq, int P, int4** probe, int32_t** nprobe) {
+    const size_t pb = (static_cast<size_t>(nq) * c->TD * P * 16 + 255) & ~size_t(255);
+    *probe = static_cast<int4*>(buf);
+    *nprobe = reinterpret_cast<int32_t*>(static_cast<char*>(buf) + pb);
+}
+}  // namespace
+extern "C" {
+
+int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
+    CHECK_CTX(c);
+    if (!t) return fail(FSPANN_E_NULL, "tick is null");
+    if (t->nq_encode < 0 || t->nq_route < 0 || t->nq_refine < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    const bool E = t->nq_encode > 0, R = t->nq_route > 0, F = t->nq_refine > 0;
+    if (!E && !R && !F) return FSPANN_OK;
+    if ((R || (F && t->ref_handover_dev)) && !c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
+    if (E && !c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized. Build index first.");
+    if (E && (!t->enc_q_dev || !t->enc_codes_dev)) return fail(FSPANN_E_NULL, "query vector is null");
+    if (R && !t->route_codes_dev) return fail(FSPANN_E_STATE, "MSANNP violation: QueryToken missing BitSet codes");
+    if (R && (!t->route_ids_dev || !t->route_count_dev)) return fail(FSPANN_E_NULL, "output buffer is null");
+    if (R && t->route_limit <= 0) return fail(FSPANN_E_ARG, "limit must be > 0");
+    if (F && (t->ref_B <= 0 || t->ref_B > INT32_MAX)) return fail(FSPANN_E_ARG, "B out of range");
+    if (F && t->k <= 0) return fail(FSPANN_E_ARG, "topK must be > 0");
+    if (F && (!t->ref_q_dev || !t->ref_ids_dev || !t->ref_count_dev || !t->out_ids_dev || !t->out_dist_dev || !t->out_count_dev))
+        return fail(FSPANN_E_NULL, "refine buffer is null");
+    if (F && !t->ref_cand_dev && !c->d_store) return fail(FSPANN_E_STATE, "plaintext store not set");
+    if (F && ((t->ref_handover_dev != nullptr) != (t->ref_codes_dev != nullptr)))
+        return fail(FSPANN_E_ARG, "ref_handover_dev and ref_codes_dev go together (the batch's codes and the buffer its Route wrote)");
+    const bool gather = F && !t->ref_cand_dev;
+    const int d = c->cfg.dim;
+    int rc;
+
+    // ---- Route of the batch being routed; Route parameters of the batch being refined (to finish its PENDING queries)
+    RoutePlan plR{}, plX{};
+    RouteParams pR{}, pX{};
+    bool fusedR = false, fusedX = false;
+    if (R) {
+        if ((rc = prepare_route(c, t->nq_route, t->route_codes_dev, t->route_probe_override, t->route_limit, t->route_limit, t->route_ids_dev,
+                                nullptr, t->route_count_dev, nullptr, nullptr, &plR, &pR, &fusedR))) return rc;
+        if (t->route_handover_dev) handover_ptrs(c, t->route_handover_dev, t->nq_route, plR.P, &pR.probe_g, &pR.nprobe_g);
+    }
+    const bool fix = F && t->ref_handover_dev != nullptr;
+    if (fix) {
+        if ((rc = prepare_route(c, t->nq_refine, t->ref_codes_dev, t->ref_probe_override, static_cast<int32_t>(t->ref_B), t->ref_B, t->ref_ids_dev,
+                                nullptr, t->ref_count_dev, nullptr, nullptr, &plX, &pX, &fusedX))) return rc;
+        handover_ptrs(c, t->ref_handover_dev, t->nq_refine, plX.P, &pX.probe_g, &pX.nprobe_g);
+        // the redo runs with its arena in global memory: one slice (+ sort buffer for degenerate tie groups) per refine workgroup
+        const int full_sort = next_pow2(std::max(plX.maxcand, 1));
+        pX.sort_cap = std::min(full_sort, 1024);
+        const size_t arena = ((static_cast<size_t>(pX.sort_cap) * 8 + static_cast<size_t>(plX.ht_size) * 4 + static_cast<size_t>(plX.max_tuples) * 4 +
+                               ((static_cast<size_t>(plX.max_tuples) * 2 + 15) & ~size_t(15))) + 255) & ~size_t(255);
+        const int64_t gstride = (pX.sort_cap < full_sort) ? full_sort : 0;
+        const int64_t fix_wgs = std::min<int64_t>(t->nq_refine, static_cast<int64_t>(c->num_cus) * c->knob_tick_refine);   // one slice per refine workgroup
+        const size_t so = static_cast<size_t>(fix_wgs) * gstride * 8;
+        if ((rc = ensure(c, c->ws_tickfix, static_cast<size_t>(fix_wgs) * arena + so + 512))) return rc;
+        pX.g_sort = so ? static_cast<uint64_t*>(c->ws_tickfix.p) : nullptr;
+        pX.g_sort_stride = gstride;
+        pX.g_scratch = static_cast<unsigned char*>(c->ws_tickfix.p) + ((so + 255) & ~size_t(255));
+        pX.g_stride = static_cast<int64_t>(arena);
+        pX.qcount = nullptr; pX.qlist = nullptr;
+    }
+
+    // ---- can the three roles share one kernel?
+    const int nchunks = F ? static_cast<int>((t->ref_B + kRefRows - 1) / kRefRows) : 1;
+    const void* rows = gather ? c->d_store : t->ref_cand_dev;
+    const int rows_dtype = gather ? c->store_dtype : t->ref_cand_dtype;
+    bool fuse = c->knob_tick_fuse != 0;
+    if (E) fuse = fuse && t->enc_dtype == FSPANN_F32;
+    if (R) fuse = fuse && plR.lazy && fusedR;
+    if (F) fuse = fuse && t->ref_q_dtype == FSPANN_F32 && rows_dtype == FSPANN_F32 && nchunks == 1 && (d % 4 == 0) &&
+                  ((reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+    const size_t lds_ref = static_cast<size_t>(kRefRows) * (32 + 4) * sizeof(float);
+    const size_t lds_enc = static_cast<size_t>(kTickEncQB * kEncThreads + kTickEncQB) * 4;
+    size_t lds = 0;
+    if (E) lds = std::max(lds, lds_enc);
+    if (R) lds = std::max(lds, plR.lz_lds_bytes);
+    if (F) lds = std::max(lds, lds_ref);
+    if (fix) lds = std::max(lds, plX.small_bytes);
+    fuse = fuse && lds + 1024 <= static_cast<size_t>(c->lds_limit);
+    c->last_tick_fused = fuse ? 1 : 0;
+
+    if (!fuse) {   // stand-alone kernels in stream order: same results
+        if (fix) {
+            auto fk = tick_fix_kernel;
+            if (!(c->attr_mask & 64u)) {
+                FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                c->attr_mask |= 64u;
+            }
+            hipLaunchKernelGGL(fk, dim3(static_cast<unsigned>(t->nq_refine)), dim3(kTickThreads), plX.small_bytes, c->stream, pX);
+            FSP_HIP(hipGetLastError());
+        }
+        if (F) {
+            rc = gather ? fspann_refine_store_dev(c, t->nq_refine, t->ref_q_dev, t->ref_q_dtype, t->ref_B, t->ref_ids_dev, t->ref_count_dev, t->k,
+                                                  t->out_ids_dev, t->out_dist_dev, t->out_count_dev, t->scored_dev)
+                        : fspann_refine_dev(c, t->nq_refine, t->ref_q_dev, t->ref_q_dtype, t->ref_cand_dev, t->ref_cand_dtype, t->ref_B, t->ref_ids_dev,
+                                            t->ref_count_dev, t->k, t->out_ids_dev, t->out_dist_dev, t->out_count_dev, t->scored_dev);
+            if (rc) return rc;
+        }
+        if (R) {
+            // the stand-alone call finishes handed-over queries itself (second launch); a hand-over buffer then stays unused
+            if ((rc = fspann_route_dev(c, t->nq_route, t->route_codes_dev, t->route_probe_override, t->route_limit, t->route_limit, t->route_ids_dev,
+                                       nullptr, t->route_count_dev, nullptr, nullptr))) return rc;
+        }
+        if (E && (rc = fspann_encode_dev(c, t->nq_encode, t->enc_q_dev, t->enc_dtype, t->enc_codes_dev, nullptr, t->enc_bad_dev))) return rc;
+        return FSPANN_OK;
+    }
+
+    TickHead p{};
+    EncodeArgs<float> eaT{};
+    RouteParams routeT{}, fixT{};
+    RefineArgs<float, float> raT{};
+    if (E) {
+        const int m = c->cfg.m;
+        const int tdPerBlock = std::max(1, kEncThreads / m);
+        const int gy = (c->TD + tdPerBlock - 1) / tdPerBlock;
+        p.enc_gx = static_cast<int>((t->nq_encode + kTickEncQB - 1) / kTickEncQB);
+        p.n_enc = p.enc_gx * gy;
+        eaT = EncodeArgs<float>{static_cast<const float*>(t->enc_q_dev), t->nq_encode, d, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda,
+                                  c->W, c->TD, tdPerBlock, t->enc_codes_dev, nullptr, t->enc_bad_dev, nullptr, nullptr, 0};
+        c->mfma_last = false;
+    } else p.enc_gx = 1;
+    if (R) {
+        p.n_route = static_cast<int>(std::min<int64_t>(t->nq_route, 1 << 24));   // one query per workgroup
+        routeT = pR;
+        c->last_route_lazy = 1;
+    }
+    if (F) {
+        // the scan runs as a stream: a few workgroups per CU, each walking several queries (refine_stream_run)
+        p.n_refine = static_cast<int>(std::min<int64_t>(t->nq_refine, static_cast<int64_t>(c->num_cus) * c->knob_tick_refine));
+        p.nq_refine = t->nq_refine;
+        raT = RefineArgs<float, float>{static_cast<const float*>(t->ref_q_dev), static_cast<const float*>(rows), gather ? c->store_n : 0, t->ref_B, d,
+                                         t->ref_ids_dev, t->ref_count_dev, t->k, 1, t->out_ids_dev, t->out_dist_dev, t->out_count_dev, t->scored_dev,
+                                         nullptr, nullptr};
+        p.has_fix = fix ? 1 : 0;
+        if (fix) fixT = pX;
+    }
+    // the redo's parameters live in device memory (tick.hip.h): a small cache of recently used parameter blocks, so a serving
+    // loop that cycles through a few buffer sets uploads each block once
+    const RouteParams* fix_dev = nullptr;
+    if (fix) {
+        if (!c->d_fixparams) {
+            FSP_HIP(hipMalloc(&c->d_fixparams, sizeof(RouteParams) * fspann_ctx::kFixSlots));
+            c->h_fixparams.assign(sizeof(RouteParams) * fspann_ctx::kFixSlots, 0);
+            c->fix_valid = 0;
+        }
+        int slot = -1;
+        for (int i = 0; i < fspann_ctx::kFixSlots; i++)
+            if (((c->fix_valid >> i) & 1u) && std::memcmp(c->h_fixparams.data() + sizeof(RouteParams) * i, &fixT, sizeof(RouteParams)) == 0) { slot = i; break; }
+        if (slot < 0) {
+            slot = c->fix_next;
+            c->fix_next = (c->fix_next + 1) % fspann_ctx::kFixSlots;
+            std::memcpy(c->h_fixparams.data() + sizeof(RouteParams) * slot, &fixT, sizeof(RouteParams));
+            // stream-ordered: ticks already enqueued that read this slot run before the copy
+            FSP_HIP(hipMemcpyAsync(static_cast<char*>(c->d_fixparams) + sizeof(RouteParams) * slot, &fixT, sizeof(RouteParams), hipMemcpyHostToDevice, c->stream));
+            c->fix_valid |= 1u << slot;
+        }
+        fix_dev = reinterpret_cast<const RouteParams*>(static_cast<char*>(c->d_fixparams) + sizeof(RouteParams) * slot);
+    }
+    // long jobs first: a share of the Route workgroups heads the grid, the rest is spread evenly between the others
+    p.route_front = F ? static_cast<int>(static_cast<int64_t>(p.n_route) * c->knob_tick_front / 100) : p.n_route;
+    p.dbg = c->dbg_route;           // debug builds: the tick's own per-workgroup stamps (the roles' phase stamps stay off)
+    routeT.dbg = nullptr;
+    fixT.dbg = nullptr;
+    const int64_t total = static_cast<int64_t>(p.n_enc) + p.n_route + p.n_refine;
+    if (total > INT32_MAX) return fail(FSPANN_E_RANGE, "too many workgroups in one tick");
+    auto launch = [&](auto kern, unsigned abit) -> int {
+        if (!(c->attr_mask & abit)) {
+            FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+            c->attr_mask |= abit;
+        }
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(total)), dim3(kTickThreads), lds, c->stream, p, eaT, routeT, fix_dev, raT);
+        FSP_HIP(hipGetLastError());
+        return FSPANN_OK;
+    };
+    if ((rc = gather ? launch(tick_kernel<true>, 128u) : launch(tick_kernel<false>, 256u))) return rc;
+    if (R && !t->route_handover_dev) {
+        // no buffer travels with the batch: queries the bounded select handed over are finished now (normally none)
+        RouteParams q2 = pR;
+        q2.qcount = pR.ovf_count; q2.qlist = pR.ovf_list;
+        const int g2 = std::min(plR.grid, 32);
+        auto kern = route_select_kernel<true, 512>;
+        if (plR.lds_mode && plR.threads == 512) {
+            if (!(c->attr_mask & 1u)) {
+                FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                c->attr_mask |= 1u;
+            }
+            hipLaunchKernelGGL(kern, dim3(g2), dim3(512), plR.lds_bytes, c->stream, q2, q2.probe_g, q2.nprobe_g);
+            FSP_HIP(hipGetLastError());
+        } else {
+            return fail(FSPANN_E_STATE, "tick: hand-over buffer required for this configuration");
+        }
+    }
+    return FSPANN_OK;
 }
 
 const void* fspann_store_dev_ptr(fspann_ctx* c, int* dtype) {

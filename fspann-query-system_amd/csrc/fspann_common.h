@@ -85,6 +85,11 @@ struct fspann_ctx {
     int knob_lazy_cap = 0;           // FSPANN_ROUTE_LAZY_CAP: entries one query may hold in the bounded select (tests)
     int knob_fused_probe = 1;        // FSPANN_ROUTE_FUSED_PROBE=0: separate probe kernel in front of the bounded select
     int knob_refine_dc = 0;          // FSPANN_REFINE_DC: dims per LDS tile of the refinement scan (tools/refine_bench.py)
+    int knob_refine_stream = 2;      // FSPANN_REFINE_STREAM: workgroups per CU of the streaming refinement scan (0: one workgroup per query)
+    int knob_tick_refine = 1;        // FSPANN_TICK_REFINE: refine workgroups per CU inside a tick (each streams several queries)
+    int knob_tick_fuse = 1;          // FSPANN_TICK_FUSE=0: fspann_tick_dev always uses the stand-alone kernels
+    int knob_tick_front = 50;        // FSPANN_TICK_FRONT: percent of a tick's Route workgroups that head the grid
+    int last_tick_fused = 0;
 
     // GFunctions: alphaT[dim][P_total] fp64 (transposed for coalescing), r/omega[P_total]
     double* d_alphaT = nullptr;
@@ -145,6 +150,12 @@ struct fspann_ctx {
     fspann::DevBuf ws_route;   // global hash/sort fallback for the route kernel
     fspann::DevBuf ws_probe;   // probe lists handed from route_probe_kernel to route_select_kernel
     fspann::DevBuf ws_refine;  // per-chunk partial top-k
+    fspann::DevBuf ws_tickfix; // arenas of the full select run by the refine role of a tick for PENDING queries
+    static constexpr int kFixSlots = 8;
+    void* d_fixparams = nullptr;         // kFixSlots RouteParams blocks in device memory (parameters of that redo) ...
+    std::vector<unsigned char> h_fixparams;   // ... and what each slot holds
+    unsigned fix_valid = 0;
+    int fix_next = 0;
     fspann::DevBuf ws_io[8];   // staging for the host-pointer entry points
 };
 

@@ -22,6 +22,7 @@
 namespace fspann {
 
 constexpr int kRefRows = 256;     // rows (= lanes) per workgroup
+constexpr int kRefCountUnknown = -0x7FFFFFFF;
 constexpr uint64_t kInvalidKey = ~0ull;
 
 struct RefinePartial {  // one per (query, chunk, rank)
@@ -69,138 +70,41 @@ __device__ __forceinline__ int rank_among(const uint64_t* keys, int n, uint64_t 
 // QSI:238-271 produced it).  GATHER = true: `cand` is the device-resident plaintext store [store_n][d] and row j of
 // query qi is store[cand_ids[qi*B + j]] — the rows are read from the store exactly once, no staging copy; an id
 // outside [0, store_n) is a point that failed to load (QSI:252-256: skipped, not scored).
-template <typename TC, typename TQ, int DC, bool VEC, bool GATHER>
-__global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeof(TC) <= 256 ? 2 : 1))) void refine_scan_kernel(
-    const TQ* __restrict__ q, const TC* __restrict__ cand, int64_t store_n, int64_t B, int d, const int32_t* __restrict__ cand_ids,
-    const int32_t* __restrict__ cand_count, int k, int nchunks, int32_t* __restrict__ out_ids,
-    double* __restrict__ out_dist, int32_t* __restrict__ out_count, int32_t* __restrict__ scored,
-    RefinePartial* __restrict__ partial, int32_t* __restrict__ partial_cnt) {
-    using V = typename VecOf<TC>::type;
-    constexpr int VN = VecOf<TC>::N;
-    constexpr int PITCH = VEC ? DC + VN : DC + 1;   // elements per LDS row
-    constexpr int VPR = DC / VN;                    // 16-byte vectors per row per tile
-    // LDS budget: <= 40 KB per workgroup so that FOUR workgroups (all 1024 of a 1024-query batch) are resident per
-    // CU; the top-k scratch (keys, surv) therefore aliases the tile, which is dead once the scan loop is done, and
-    // the query vector is not staged at all: its address is wave-uniform, so it is read through the scalar cache.
-    extern __shared__ __align__(16) unsigned char smem[];
-    TC* tile = reinterpret_cast<TC*>(smem);                                              // [kRefRows][PITCH]
+// Arguments of one refinement scan (one launch, or the refine role of tick_kernel).
+template <typename TC, typename TQ>
+struct RefineArgs {
+    const TQ* q;
+    const TC* cand;              // dense [nq][B][d] block, or the store [store_n][d] (GATHER)
+    int64_t store_n, B;
+    int d;
+    const int32_t* cand_ids;
+    const int32_t* cand_count;
+    int k, nchunks;
+    int32_t* out_ids;
+    double* out_dist;
+    int32_t* out_count;
+    int32_t* scored;
+    RefinePartial* partial;
+    int32_t* partial_cnt;
+};
+
+// Stage C for one 256-row chunk (QSI:298-316): stable rank of the chunk's distances by (fp64 bits, candidate position),
+// the first min(k, valid) written out (or handed to refine_merge_kernel as a partial list when B spans several chunks).
+// `tile` = the workgroup's LDS tile, dead at this point: every wave keeps its scratch in its own 64 rows of it.
+template <typename TC, typename TQ, int PITCH>
+__device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC* tile, const bool valid, const uint64_t key,
+                                                 const int32_t my_id, const int64_t qi, const int chunk, const int r0) {
+    const int k = a.k, nchunks = a.nchunks;
+    int32_t* __restrict__ out_ids = a.out_ids;
+    double* __restrict__ out_dist = a.out_dist;
+    int32_t* __restrict__ out_count = a.out_count;
+    int32_t* __restrict__ scored = a.scored;
+    RefinePartial* __restrict__ partial = a.partial;
+    int32_t* __restrict__ partial_cnt = a.partial_cnt;
     __shared__ uint64_t s_wcut[kRefRows / 64];
     __shared__ int s_wbase[kRefRows / 64], s_wsurvn[kRefRows / 64];
-    const TQ* __restrict__ qrow = q + static_cast<int64_t>(blockIdx.x / nchunks) * d;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int64_t qi = blockIdx.x / nchunks;
-    const int chunk = blockIdx.x - static_cast<int>(qi) * nchunks;
-    const int r0 = chunk * kRefRows;
-    const TC* base = GATHER ? cand : cand + (qi * B + r0) * static_cast<int64_t>(d);
-    // The candidate ids do not depend on cand_count: they are requested first (all slots of this chunk that exist in
-    // the [nq][B] id array), so the count, the ids and the query check are ONE global round trip before the rows.
-    const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
-    const int32_t my_id_raw = (tid < rows_here) ? cand_ids[qi * B + r0 + tid] : -1;
-    // register double buffering: tile t+1 is in flight (global -> VGPR) while tile t is consumed from LDS
-    V reg[VPR];
-    // source row of each of this lane's 16-byte slots: the block-local row (dense) or the store row (gather), -1 = none
-    int32_t srow[VPR];
-    if constexpr (VEC && GATHER) {
-#pragma unroll
-        for (int i = 0; i < VPR; i++) {
-            const int row = wave * 64 + (lane + i * 64) / VPR;
-            srow[i] = (row < rows_here) ? cand_ids[qi * B + r0 + row] : -1;
-        }
-    }
-    // QSI.java:137-140: a non-finite query gives an empty result.  Every wave looks at the whole query itself.
-    bool qnf = false;
-    for (int i = lane; i < d; i += 64) qnf = qnf || !__builtin_isfinite(qrow[i]);
-    const bool qbad = __any(qnf);
-    const int cnt = static_cast<int>(min(static_cast<int64_t>(cand_count[qi]), B));
-    const int nrows = max(0, min(kRefRows, cnt - r0));
-    // candidate id of this lane's row (the epilogue has no dependent global load)
-    const int32_t my_id = (tid < nrows) ? my_id_raw : -1;
-    if constexpr (VEC) {
-#pragma unroll
-        for (int i = 0; i < VPR; i++) {
-            const int row = wave * 64 + (lane + i * 64) / VPR;
-            if constexpr (GATHER) srow[i] = (row < nrows && srow[i] >= 0 && srow[i] < store_n) ? srow[i] : -1;
-            else srow[i] = (row < nrows) ? row : -1;
-        }
-    }
-#define FSP_ISSUE(C0)                                                                                              \
-    if constexpr (VEC) {                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                          \
-            const int col = (C0) + ((lane + i * 64) % VPR) * VN;                                                   \
-            if (srow[i] >= 0 && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(srow[i]) * d + col); \
-        }                                                                                                          \
-    }
-    double s = 0.0;
-    bool ok = GATHER ? (my_id >= 0 && my_id < store_n) : true;
-    FSP_ISSUE(0)
-    // Each wave stages and consumes ITS OWN 64 rows: no workgroup barrier in the loop, the four waves drift apart
-    // and overlap each other's load / LDS / fp64 phases.  LDS operations of one wave complete in program order.
-#define FSP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-    for (int c0 = 0; c0 < d; c0 += DC) {
-        FSP_WAVE_SYNC();  // previous tile fully consumed by this wave
-        if constexpr (VEC) {
-#pragma unroll
-            for (int i = 0; i < VPR; i++) {
-                const int v = lane + i * 64;
-                const int row = wave * 64 + v / VPR, cv = v % VPR;
-                const int col = c0 + cv * VN;
-                if (srow[i] >= 0 && col < d) *reinterpret_cast<V*>(tile + row * PITCH + cv * VN) = reg[i];
-            }
-        } else {
-            for (int e = lane; e < 64 * DC; e += 64) {
-                const int row = wave * 64 + e / DC, cc = e % DC;
-                if (row < nrows && c0 + cc < d) {
-                    int64_t sr = row;
-                    if constexpr (GATHER) {
-                        const int32_t id = cand_ids[qi * B + r0 + row];
-                        sr = (id >= 0 && id < store_n) ? id : -1;
-                    }
-                    if (sr >= 0) tile[row * PITCH + cc] = base[sr * d + c0 + cc];
-                }
-            }
-        }
-        if (c0 + DC < d) { FSP_ISSUE(c0 + DC) }
-        FSP_WAVE_SYNC();
-        if (tid < nrows) {
-            const int dc = min(DC, d - c0);
-            const TC* myrow = tile + tid * PITCH;
-            if constexpr (VEC) {
-#pragma unroll 4
-                for (int kk = 0; kk < dc; kk += VN) {
-                    const V xv = *reinterpret_cast<const V*>(myrow + kk);
-#pragma unroll
-                    for (int e = 0; e < VN; e += 2) {
-                        const double q0 = static_cast<double>(qrow[c0 + kk + e]);      // uniform address -> scalar load
-                        const double q1 = static_cast<double>(qrow[c0 + kk + e + 1]);
-                        ok = ok && __builtin_isfinite(xv[e]) && __builtin_isfinite(xv[e + 1]);   // v_cmp_class on the raw element
-                        const double x0 = vcomp(xv, e), x1 = vcomp(xv, e + 1);   // exact widening
-                        const double d0 = q0 - x0;                               // QSI.java:368
-                        const double p0 = d0 * d0;
-                        s = s + p0;                                              // QSI.java:369 (in order)
-                        const double d1 = q1 - x1;
-                        const double p1 = d1 * d1;
-                        s = s + p1;
-                    }
-                }
-            } else {
-                for (int kk = 0; kk < dc; kk++) {
-                    const TC x = myrow[kk];
-                    ok = ok && finite_t(x);
-                    const double dd = static_cast<double>(qrow[c0 + kk]) - static_cast<double>(x);
-                    const double sq = dd * dd;
-                    s = s + sq;
-                }
-            }
-        }
-    }
-#undef FSP_ISSUE
-#undef FSP_WAVE_SYNC
-    const bool valid = (tid < nrows) && ok && !qbad;
-    uint64_t key = kInvalidKey;
-    if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
-
     // ---- stable rank by (distance bits, candidate position) -------------------------------------
     // Scratch lives in each wave's OWN (now dead) tile rows, so the per-wave steps need no workgroup barrier:
     //   wkeys[64]  the wave's keys           wsurv[64]  the wave's survivors (keys <= the chunk-wide cut)
@@ -296,6 +200,318 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
             partial_cnt[(qi * nchunks + chunk) * 2 + 1] = nvalid;
         }
     }
+}
+
+// One workgroup (kRefRows threads) = one 256-row chunk of one query: block `bidx` of nq * nchunks.  `smem` = dynamic LDS.
+template <typename TC, typename TQ, int DC, bool VEC, bool GATHER>
+__device__ __forceinline__ void refine_scan_block(const RefineArgs<TC, TQ>& a, unsigned char* smem, const int64_t bidx,
+                                                  const int cnt_known = kRefCountUnknown) {
+    const TQ* __restrict__ q = a.q;
+    const TC* __restrict__ cand = a.cand;
+    const int64_t store_n = a.store_n, B = a.B;
+    const int d = a.d, nchunks = a.nchunks;
+    const int32_t* __restrict__ cand_ids = a.cand_ids;
+    const int32_t* __restrict__ cand_count = a.cand_count;
+    using V = typename VecOf<TC>::type;
+    constexpr int VN = VecOf<TC>::N;
+    constexpr int PITCH = VEC ? DC + VN : DC + 1;   // elements per LDS row
+    constexpr int VPR = DC / VN;                    // 16-byte vectors per row per tile
+    // LDS budget: <= 40 KB per workgroup so that FOUR workgroups (all 1024 of a 1024-query batch) are resident per
+    // CU; the top-k scratch (keys, surv) therefore aliases the tile, which is dead once the scan loop is done, and
+    // the query vector is not staged at all: its address is wave-uniform, so it is read through the scalar cache.
+    TC* tile = reinterpret_cast<TC*>(smem);                                              // [kRefRows][PITCH]
+    const TQ* __restrict__ qrow = q + (bidx / nchunks) * d;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t qi = bidx / nchunks;
+    const int chunk = static_cast<int>(bidx - qi * nchunks);
+    const int r0 = chunk * kRefRows;
+    const TC* base = GATHER ? cand : cand + (qi * B + r0) * static_cast<int64_t>(d);
+    // The candidate ids do not depend on cand_count: they are requested first (all slots of this chunk that exist in
+    // the [nq][B] id array), so the count, the ids and the query check are ONE global round trip before the rows.
+    const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
+    const int32_t my_id_raw = (tid < rows_here) ? cand_ids[qi * B + r0 + tid] : -1;
+    // register double buffering: tile t+1 is in flight (global -> VGPR) while tile t is consumed from LDS
+    V reg[VPR];
+    // source row of each of this lane's 16-byte slots: the block-local row (dense) or the store row (gather), -1 = none
+    int32_t srow[VPR];
+    if constexpr (VEC && GATHER) {
+#pragma unroll
+        for (int i = 0; i < VPR; i++) {
+            const int row = wave * 64 + (lane + i * 64) / VPR;
+            srow[i] = (row < rows_here) ? cand_ids[qi * B + r0 + row] : -1;
+        }
+    }
+    // QSI.java:137-140: a non-finite query gives an empty result.  Every wave looks at the whole query itself.
+    bool qnf = false;
+    for (int i = lane; i < d; i += 64) qnf = qnf || !__builtin_isfinite(qrow[i]);
+    const bool qbad = __any(qnf);
+    // cnt_known: the caller has read cand_count[qi] itself (tick_kernel re-reads it after redoing a PENDING query's Route)
+    const int cnt = static_cast<int>(min(static_cast<int64_t>(cnt_known != kRefCountUnknown ? cnt_known : cand_count[qi]), B));
+    const int nrows = max(0, min(kRefRows, cnt - r0));
+    // candidate id of this lane's row (the epilogue has no dependent global load)
+    const int32_t my_id = (tid < nrows) ? my_id_raw : -1;
+    if constexpr (VEC) {
+#pragma unroll
+        for (int i = 0; i < VPR; i++) {
+            const int row = wave * 64 + (lane + i * 64) / VPR;
+            if constexpr (GATHER) srow[i] = (row < nrows && srow[i] >= 0 && srow[i] < store_n) ? srow[i] : -1;
+            else srow[i] = (row < nrows) ? row : -1;
+        }
+    }
+#define FSP_ISSUE(C0)                                                                                              \
+    if constexpr (VEC) {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                          \
+            const int col = (C0) + ((lane + i * 64) % VPR) * VN;                                                   \
+            if (srow[i] >= 0 && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(srow[i]) * d + col); \
+        }                                                                                                          \
+    }
+    double s = 0.0;
+    bool ok = GATHER ? (my_id >= 0 && my_id < store_n) : true;
+    FSP_ISSUE(0)
+    // Each wave stages and consumes ITS OWN 64 rows: no workgroup barrier in the loop, the four waves drift apart
+    // and overlap each other's load / LDS / fp64 phases.  LDS operations of one wave complete in program order.
+#define FSP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    for (int c0 = 0; c0 < d; c0 += DC) {
+        FSP_WAVE_SYNC();  // previous tile fully consumed by this wave
+        if constexpr (VEC) {
+#pragma unroll
+            for (int i = 0; i < VPR; i++) {
+                const int v = lane + i * 64;
+                const int row = wave * 64 + v / VPR, cv = v % VPR;
+                const int col = c0 + cv * VN;
+                if (srow[i] >= 0 && col < d) *reinterpret_cast<V*>(tile + row * PITCH + cv * VN) = reg[i];
+            }
+        } else {
+            for (int e = lane; e < 64 * DC; e += 64) {
+                const int row = wave * 64 + e / DC, cc = e % DC;
+                if (row < nrows && c0 + cc < d) {
+                    int64_t sr = row;
+                    if constexpr (GATHER) {
+                        const int32_t id = cand_ids[qi * B + r0 + row];
+                        sr = (id >= 0 && id < store_n) ? id : -1;
+                    }
+                    if (sr >= 0) tile[row * PITCH + cc] = base[sr * d + c0 + cc];
+                }
+            }
+        }
+        if (c0 + DC < d) { FSP_ISSUE(c0 + DC) }
+        FSP_WAVE_SYNC();
+        if (tid < nrows) {
+            const int dc = min(DC, d - c0);
+            const TC* myrow = tile + tid * PITCH;
+            if constexpr (VEC) {
+#pragma unroll 4
+                for (int kk = 0; kk < dc; kk += VN) {
+                    const V xv = *reinterpret_cast<const V*>(myrow + kk);
+#pragma unroll
+                    for (int e = 0; e < VN; e += 2) {
+                        const double q0 = static_cast<double>(qrow[c0 + kk + e]);      // uniform address -> scalar load
+                        const double q1 = static_cast<double>(qrow[c0 + kk + e + 1]);
+                        ok = ok && __builtin_isfinite(xv[e]) && __builtin_isfinite(xv[e + 1]);   // v_cmp_class on the raw element
+                        const double x0 = vcomp(xv, e), x1 = vcomp(xv, e + 1);   // exact widening
+                        const double d0 = q0 - x0;                               // QSI.java:368
+                        const double p0 = d0 * d0;
+                        s = s + p0;                                              // QSI.java:369 (in order)
+                        const double d1 = q1 - x1;
+                        const double p1 = d1 * d1;
+                        s = s + p1;
+                    }
+                }
+            } else {
+                for (int kk = 0; kk < dc; kk++) {
+                    const TC x = myrow[kk];
+                    ok = ok && finite_t(x);
+                    const double dd = static_cast<double>(qrow[c0 + kk]) - static_cast<double>(x);
+                    const double sq = dd * dd;
+                    s = s + sq;
+                }
+            }
+        }
+    }
+#undef FSP_ISSUE
+#undef FSP_WAVE_SYNC
+    const bool valid = (tid < nrows) && ok && !qbad;
+    uint64_t key = kInvalidKey;
+    if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
+    refine_topk_emit<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, chunk, r0);
+}
+
+template <typename TC, typename TQ, int DC, bool VEC, bool GATHER>
+__global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeof(TC) <= 256 ? 2 : 1))) void refine_scan_kernel(RefineArgs<TC, TQ> a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    refine_scan_block<TC, TQ, DC, VEC, GATHER>(a, smem, static_cast<int64_t>(blockIdx.x));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same scan as a STREAM: one workgroup walks the units (query, 256-row chunk) u = wg, wg + nwg, wg + 2 nwg, ... and
+// keeps the row loads of the next TWO tiles in flight at all times — across unit boundaries, so the loads of the next
+// query are under way while this query's top-K is ranked and written.
+//
+// Why: with one workgroup per query (refine_scan_block) every workgroup of the launch is in the same phase at the same
+// time — all wait for their ids, all stream, all rank — and HBM idles during the first and the last phase; and inside
+// tick_kernel each of those workgroups holds one of the CU's four slots for ~25 us, most of it waiting.  As a stream, a
+// quarter of the workgroups (one or two per CU) keep HBM just as busy (2 tiles x 32 KB in flight per workgroup), the
+// bubbles overlap with streaming, and the other slots are free for the latency-bound Route workgroups.
+//
+// Numerics are those of refine_scan_block: each lane walks ITS row in dimension order in fp64 (QSI:364-372), the top-K
+// is refine_topk_emit.  VEC layout only (d % (16 / sizeof(TC)) == 0, 16-byte aligned rows): the host falls back otherwise.
+// counts_fresh: read cand_count with a device-scope atomic load (tick_kernel: the count of a PENDING query was rewritten
+// by this very workgroup a moment ago; a plain load could hit a stale scalar / L1 line).
+template <typename TC, typename TQ, int DC, bool GATHER>
+__device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, unsigned char* smem, const int64_t wg, const int64_t nwg,
+                                                  const int64_t nq, const bool counts_fresh) {
+    using V = typename VecOf<TC>::type;
+    constexpr int VN = VecOf<TC>::N;
+    constexpr int PITCH = DC + VN;
+    constexpr int VPR = DC / VN;
+    const TC* __restrict__ cand = a.cand;
+    const int64_t store_n = a.store_n, B = a.B;
+    const int d = a.d, nchunks = a.nchunks;
+    const int32_t* __restrict__ cand_ids = a.cand_ids;
+    TC* tile = reinterpret_cast<TC*>(smem);                                              // [kRefRows][PITCH]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ntile = (d + DC - 1) / DC;
+    const int64_t nunits = nq * nchunks;
+    const int slot_row = wave * 64 + lane / VPR;          // + i * (64 / VPR): row of this lane's i-th 16-byte slot
+    const int slot_col = (lane % VPR) * VN;               // column of the slot inside a tile
+
+    // ---- issue side: position (unit, tile) two tiles ahead of the consume side -----------------------------------
+    int64_t iu = wg;                                       // unit being requested
+    int it = 0;                                            // its next tile
+    // Every load of the stream is UNCONDITIONAL (a slot without a row — beyond the block's rows, an id outside the store,
+    // a column beyond d in a partial last tile — re-reads a row / column that exists and its data is never used): with
+    // predicated loads the compiler waits for ALL outstanding loads at every tile instead of only the older register set,
+    // and the two-tile prefetch is gone (measured: 4.7 us per tile instead of ~1.3).
+    int32_t isrc[GATHER ? VPR : 1];                        // gather: store row of each slot for unit iu (clamped into the store)
+    int irows = 1;                                         // dense: rows of unit iu that exist in the block
+    auto load_sources = [&](const int64_t u) {
+        const int64_t uu = min(u, nunits - 1);             // past the end: the last unit once more (loaded, never consumed)
+        const int64_t qi = uu / nchunks;
+        const int r0 = static_cast<int>(uu - qi * nchunks) * kRefRows;
+        const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
+        irows = rows_here;
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int i = 0; i < VPR; i++) {
+                const int row = min(slot_row + i * (64 / VPR), rows_here - 1);
+                const int32_t id = cand_ids[qi * B + r0 + row];
+                isrc[i] = (id >= 0 && id < store_n) ? id : 0;      // a point that failed to load (QSI:252-256): row 0 is read, never scored
+            }
+        }
+    };
+    auto unit_base = [&](const int64_t u) -> const TC* {
+        if constexpr (GATHER) return cand;
+        const int64_t uu = min(u, nunits - 1);
+        const int64_t qi = uu / nchunks;
+        const int r0 = static_cast<int>(uu - qi * nchunks) * kRefRows;
+        return cand + (qi * B + r0) * static_cast<int64_t>(d);
+    };
+    const TC* ibase = unit_base(iu);
+    load_sources(iu);
+#define FSP_STREAM_ISSUE(REG)                                                                                       \
+    do {                                                                                                            \
+        int col_ = it * DC + slot_col;                                                                              \
+        col_ = (col_ < d) ? col_ : 0;                                                                               \
+        _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                           \
+            const int64_t srow_ = GATHER ? static_cast<int64_t>(isrc[GATHER ? i : 0])                               \
+                                         : static_cast<int64_t>(min(slot_row + i * (64 / VPR), irows - 1));         \
+            REG[i] = *reinterpret_cast<const V*>(ibase + srow_ * d + col_);                                         \
+        }                                                                                                           \
+        if (++it == ntile) {                                                                                        \
+            it = 0;                                                                                                 \
+            iu += nwg;                                                                                              \
+            ibase = unit_base(iu);                                                                                  \
+            load_sources(iu);                                                                                       \
+        }                                                                                                           \
+    } while (0)
+#define FSP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+    V regA[VPR], regB[VPR];
+    FSP_STREAM_ISSUE(regA);
+    FSP_STREAM_ISSUE(regB);
+
+    // ---- consume side ------------------------------------------------------------------------------------------------
+    for (int64_t u = wg; u < nunits; u += nwg) {
+        const int64_t qi = u / nchunks;
+        const int chunk = static_cast<int>(u - qi * nchunks);
+        const int r0 = chunk * kRefRows;
+        // the query row through the CONSTANT address space: uniform loads from it are scalar loads whatever else the
+        // enclosing kernel does (see encode_exact_block); the query batch is an input, nothing writes it
+        typedef const TQ __attribute__((address_space(4)))* const_row_t;
+        const const_row_t qrow = (const_row_t)(a.q + qi * d);
+        const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
+        const int32_t my_id_raw = (tid < rows_here) ? cand_ids[qi * B + r0 + tid] : -1;
+        int cnt_raw;
+        if (counts_fresh) cnt_raw = __hip_atomic_load(const_cast<int32_t*>(a.cand_count) + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else cnt_raw = a.cand_count[qi];
+        // QSI.java:137-140: a non-finite query gives an empty result.  Every wave looks at the whole query itself.
+        bool qnf = false;
+        for (int i = lane; i < d; i += 64) qnf = qnf || !__builtin_isfinite(qrow[i]);
+        const bool qbad = __any(qnf);
+        const int cnt = static_cast<int>(min(static_cast<int64_t>(cnt_raw), B));
+        const int nrows = max(0, min(kRefRows, cnt - r0));
+        const int32_t my_id = (tid < nrows) ? my_id_raw : -1;
+        double s = 0.0;
+        bool ok = GATHER ? (my_id >= 0 && my_id < store_n) : true;
+
+#define FSP_STREAM_TILE(REG, C0)                                                                                    \
+        do {                                                                                                        \
+            FSP_WAVE_SYNC();  /* previous tile fully consumed by this wave */                                       \
+            _Pragma("unroll") for (int i = 0; i < VPR; i++)   /* unconditional: rows / columns without data are never read */ \
+                *reinterpret_cast<V*>(tile + (slot_row + i * (64 / VPR)) * PITCH + slot_col) = REG[i];               \
+            FSP_STREAM_ISSUE(REG);                                                                                  \
+            FSP_WAVE_SYNC();                                                                                        \
+            if (tid < nrows) {                                                                                      \
+                const int dc = min(DC, d - (C0));                                                                   \
+                const TC* myrow = tile + tid * PITCH;                                                               \
+                _Pragma("unroll 4") for (int kk = 0; kk < dc; kk += VN) {                                           \
+                    const V xv = *reinterpret_cast<const V*>(myrow + kk);                                           \
+                    _Pragma("unroll") for (int e = 0; e < VN; e += 2) {                                             \
+                        const double q0 = static_cast<double>(qrow[(C0) + kk + e]);      /* uniform address -> scalar load */ \
+                        const double q1 = static_cast<double>(qrow[(C0) + kk + e + 1]);                             \
+                        ok = ok && __builtin_isfinite(xv[e]) && __builtin_isfinite(xv[e + 1]);                      \
+                        const double x0 = vcomp(xv, e), x1 = vcomp(xv, e + 1);   /* exact widening */                \
+                        const double d0 = q0 - x0;                               /* QSI.java:368 */                  \
+                        const double p0 = d0 * d0;                                                                  \
+                        s = s + p0;                                              /* QSI.java:369 (in order) */       \
+                        const double d1 = q1 - x1;                                                                  \
+                        const double p1 = d1 * d1;                                                                  \
+                        s = s + p1;                                                                                 \
+                    }                                                                                               \
+                }                                                                                                   \
+            }                                                                                                       \
+        } while (0)
+
+        // tiles of this unit, two per trip: the register sets alternate along the whole stream (A, B, A, B, ...)
+        for (int t = 0; t < ntile; t += 2) {
+            FSP_STREAM_TILE(regA, t * DC);
+            if (t + 1 < ntile) {
+                FSP_STREAM_TILE(regB, (t + 1) * DC);
+            } else {
+                // odd tile count (d not a multiple of 2 DC; none of the BASELINE shapes): the next unit's first tile sits in
+                // set B and its second in set A — exchange them (waits for those loads: correct, just not overlapped)
+#pragma unroll
+                for (int i = 0; i < VPR; i++) { const V tmp = regA[i]; regA[i] = regB[i]; regB[i] = tmp; }
+            }
+        }
+        const bool valid = (tid < nrows) && ok && !qbad;
+        uint64_t key = kInvalidKey;
+        if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
+        refine_topk_emit<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, chunk, r0);
+        __syncthreads();       // every wave has finished reading the other waves' scratch before the tile is written again
+    }
+#undef FSP_STREAM_TILE
+#undef FSP_STREAM_ISSUE
+#undef FSP_WAVE_SYNC
+}
+
+template <typename TC, typename TQ, int DC, bool GATHER>
+__global__ __launch_bounds__(kRefRows, 2) void refine_stream_kernel(RefineArgs<TC, TQ> a, int64_t nq) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    refine_stream_run<TC, TQ, DC, GATHER>(a, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), nq, false);
 }
 
 // Merge of per-chunk sorted top-k lists (B > kRefRows).  Each list is sorted by

@@ -73,10 +73,12 @@ struct RouteParams {
     int lazy_cap;                  // tuples one query may insert before it is handed to route_select_kernel
     int lz_ht_size, lz_ht_shift;
     int32_t* ovf_next;             // the OTHER overflow counter: zeroed by the lazy kernel for the next call (ping-pong)
+    int4* probe_g;                 // [nq][TD*P] / [nq][TD] global probe lists: written by route_probe_kernel, or by the bounded
+    int32_t* nprobe_g;             //   select itself (fused probe) when it hands a query to route_select_query
     int probe_G;                   // fused probe: lanes per table (0: the probe list comes from route_probe_kernel)
-    int32_t* ovf_count;            // overflow list written by the lazy kernel ...
+    int32_t* ovf_count;            // overflow list written by the bounded select ...
     int32_t* ovf_list;
-    const int32_t* qcount;         // ... and consumed by route_select_kernel (qlist mode: only these queries)
+    const int32_t* qcount;         // ... and consumed by route_select_kernel (list mode: only these queries)
     const int32_t* qlist;
     int32_t* unmodelled;           // context-wide count of queries whose HashMap would have treeified a bin (out_count = -1)
     long long* dbg;                // FSPANN_DEBUG_STAMPS builds: [grid][16] wall_clock64 stamps of each block's first query (else unused)
@@ -122,6 +124,8 @@ __device__ __forceinline__ void bitonic_sort_u64(PtrT sb, int n2, int tid, int n
 }
 
 constexpr uint32_t kHtEmpty = 0xFFFFFFFFu;
+constexpr int32_t kRouteUnmodelled = -1;   // out_count: a HashMap bin would be treeified, the JVM's order is not modelled
+constexpr int32_t kRoutePending = -2;      // out_count: handed over by the bounded select, the full select has not run yet
 constexpr uint16_t kFirstFlag = 0x8000u;  // tscore: first occurrence of its id (score in the low 14 bits)
 constexpr int kRankSortMax = 1024;
 
@@ -330,12 +334,13 @@ __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams 
 // ------------------------------------------------------------------------------------------
 // Kernel 2: stage ids, dedupe, Java order, select.  One workgroup per query.
 // ------------------------------------------------------------------------------------------
+// One query, one workgroup of kThreads threads.  `smem` = the workgroup's dynamic LDS; `block_id` selects this workgroup's
+// slice of the global fallback arenas (g_scratch / g_sort); probe_q [TD*P] / nprobe_q [TD] = the probe lists of THIS query
+// (global memory).  Every thread of the workgroup must call (barriers inside).  Also called from the bounded select
+// (route_lazy.hip.h) for a query it cannot hold: kLds = false there, so only the small arrays live in LDS.
 template <bool kLds, int kThreads>
-__global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams prm, const int4* __restrict__ probe_in,
-                                                                const int32_t* __restrict__ nprobe_in) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    // list mode (hand-back of the bounded select): normally the list is empty — leave before anything else is touched
-    if (prm.qlist && *prm.qcount == 0) return;
+__device__ __forceinline__ void route_select_query(const RouteParams& prm, unsigned char* smem, int block_id, const int4* __restrict__ probe_q,
+                                   const int32_t* __restrict__ nprobe_q, const int64_t qi) {
     const int tid = threadIdx.x;
     constexpr int nthreads = kThreads;
     const int lane = tid & 63, wave = tid >> 6;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
     const int TP = TD * P;
 
     // ---- carve the per-query arrays (LDS, or the global arena when they do not fit) -----
-    unsigned char* arena = kLds ? smem : prm.g_scratch + static_cast<int64_t>(blockIdx.x) * prm.g_stride;
+    unsigned char* arena = kLds ? smem : prm.g_scratch + static_cast<int64_t>(block_id) * prm.g_stride;
     size_t o = 0;
     uint64_t* sortbuf = reinterpret_cast<uint64_t*>(arena + o);  o += static_cast<size_t>(prm.sort_cap) * 8;
     uint32_t* ht = reinterpret_cast<uint32_t*>(arena + o);       o += static_cast<size_t>(prm.ht_size) * 4;
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
 
 #ifdef FSPANN_DEBUG_STAMPS
-#define FSP_STAMP(i) do { if (prm.dbg && tid == 0 && qq == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define FSP_STAMP(i) do { if (prm.dbg && tid == 0 && qi == block_id) prm.dbg[block_id * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define FSP_STAMP(i) do { } while (0)
 #endif
@@ -395,9 +400,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
         return slot;
     };
 
-    const int64_t nq_eff = prm.qlist ? static_cast<int64_t>(*prm.qcount) : prm.nq;
-    for (int64_t qq = blockIdx.x; qq < nq_eff; qq += gridDim.x) {
-        const int64_t qi = prm.qlist ? static_cast<int64_t>(prm.qlist[qq]) : qq;
+    {
         FSP_STAMP(0);
         // ---- reset (16-byte stores) + probe list of this query -------------------------------
         {
@@ -408,8 +411,8 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
             const int nt4 = (prm.max_tuples * 2 + 15) / 16;
             for (int i = tid; i < nt4; i += nthreads) t4[i] = make_uint4(0, 0, 0, 0);
             for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;
-            for (int i = tid; i < TP; i += nthreads) { stepcnt[i] = 0; probe[i] = probe_in[qi * TP + i]; }
-            for (int i = tid; i < TD; i += nthreads) { dupcnt[i] = 0; nprobe[i] = nprobe_in[qi * TD + i]; }
+            for (int i = tid; i < TP; i += nthreads) { stepcnt[i] = 0; probe[i] = probe_q[i]; }
+            for (int i = tid; i < TD; i += nthreads) { dupcnt[i] = 0; nprobe[i] = nprobe_q[i]; }
             if (tid == 0) { s_n = 0; s_raw = 0; s_fill = 0; s_cut = 0x7FFFFFFF; s_ndup = 0; s_lvl1 = 0; s_tree = 0; s_suspect = 0; }
         }
         __syncthreads();
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
         const int b1 = s_b1;
         FSP_STAMP(11);
         // compaction of the surviving candidates: score < star, or score == star && bucket bin <= b1
-        uint64_t* gs = prm.g_sort ? prm.g_sort + static_cast<int64_t>(blockIdx.x) * prm.g_sort_stride : sortbuf;
+        uint64_t* gs = prm.g_sort ? prm.g_sort + static_cast<int64_t>(block_id) * prm.g_sort_stride : sortbuf;
         for (int j0 = 0; j0 < prm.max_tuples; j0 += nthreads) {     // uniform trip count: the ballots below need every lane
             const int j = j0 + tid;
             bool take = false;
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
         FSP_STAMP(4);
         const int nsel = s_fill;
 #ifdef FSPANN_DEBUG_STAMPS
-        if (tid == 0 && prm.dbg && qq == blockIdx.x) prm.dbg[blockIdx.x * 16 + 15] = nsel;
+        if (tid == 0 && prm.dbg && qi == block_id) prm.dbg[block_id * 16 + 15] = nsel;
 #endif
         const int nout = min(nsel, prm.limit);
         if (nsel <= kRankSortMax - 128 && prm.sort_cap >= kRankSortMax) {
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
         const bool treeified = (s_tree != 0);
         if (tid == 0) {
             if (treeified && prm.unmodelled) atomicAdd(prm.unmodelled, 1);
-            prm.out_count[qi] = treeified ? -1 : nout;
+            prm.out_count[qi] = treeified ? kRouteUnmodelled : nout;
             if (prm.out_kept) prm.out_kept[qi] = n;
             if (prm.out_raw) prm.out_raw[qi] = n + s_raw;
         }
@@ -855,6 +858,20 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams p
     }
 #undef FSP_STAMP
 #undef FSP_TS
+}
+
+template <bool kLds, int kThreads>
+__global__ __launch_bounds__(kThreads, 4) void route_select_kernel(RouteParams prm, const int4* __restrict__ probe_in,
+                                                                const int32_t* __restrict__ nprobe_in) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    // list mode (hand-back of the bounded select): normally the list is empty — leave before anything else is touched
+    if (prm.qlist && *prm.qcount == 0) return;
+    const int TP = prm.TD * prm.P;
+    const int64_t nq_eff = prm.qlist ? static_cast<int64_t>(*prm.qcount) : prm.nq;
+    for (int64_t qq = blockIdx.x; qq < nq_eff; qq += gridDim.x) {
+        const int64_t qi = prm.qlist ? static_cast<int64_t>(prm.qlist[qq]) : qq;
+        route_select_query<kLds, kThreads>(prm, smem, static_cast<int>(blockIdx.x), probe_in + qi * TP, nprobe_in + qi * prm.TD, qi);
+    }
 }
 
 }  // namespace fspann

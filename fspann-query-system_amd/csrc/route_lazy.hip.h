@@ -75,10 +75,13 @@ __device__ __forceinline__ int wave_cut1024(const int32_t* bins, int need, int l
     return __shfl(lane * 16 + bb, src);
 }
 
+// The bounded select of the queries q_first, q_first + q_stride, ... < prm.nq by ONE workgroup of kThreads threads
+// (`smem` = its dynamic LDS, `block_id` = its slice of the global fallback arena).  Called by route_select_lazy_kernel
+// and by the route role of tick_kernel (tick.hip.h).
 template <int kThreads>
-__global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RouteParams prm, int4* __restrict__ probe_in,
-                                                                        int32_t* __restrict__ nprobe_in) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned char* smem, const int64_t q_first, const int64_t q_stride, const int block_id) {
+    int4* probe_in = prm.probe_g;          // not __restrict__: a handed-over query's lists are written here and read back
+    int32_t* nprobe_in = prm.nprobe_g;
     const int tid = threadIdx.x;
     constexpr int nthreads = kThreads;
     constexpr int nwv = kThreads / 64;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
 
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
     for (int i = tid; i < kLzHtSize; i += nthreads) ht[i] = kLzEmpty;
-    if (blockIdx.x == 0 && tid == 0) *prm.ovf_next = 0;   // the other counter, for the next call (stream-ordered after this one)
+    if (block_id == 0 && tid == 0) *prm.ovf_next = 0;   // the other counter, for the next call (stream-ordered after this one)
 
     // is `id` already an entry?  (an entry of an earlier level: its score is lower, this occurrence changes nothing)
     auto present = [&](int32_t id) -> bool {
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
     };
 
 #ifdef FSPANN_DEBUG_STAMPS
-#define LZ_STAMP(i) do { if (prm.dbg && tid == 0 && qi == blockIdx.x) prm.dbg[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define LZ_STAMP(i) do { if (prm.dbg && tid == 0 && qi == block_id) prm.dbg[block_id * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define LZ_STAMP(i) do { } while (0)
 #endif
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
         }                                                                                                             \
     } while (0)
 
-    for (int64_t qi = blockIdx.x; qi < prm.nq; qi += gridDim.x) {
+    for (int64_t qi = q_first; qi < prm.nq; qi += q_stride) {
         LZ_STAMP(0);
         // ---- probe list of this query; unused steps get an impossible partition and sort last ------------------
         if (prm.probe_G > 0) {
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             LZ_STAMP(5);
             const int ncoll = s_ncoll;
 #ifdef FSPANN_DEBUG_STAMPS
-            if (tid == 0 && prm.dbg && qi == blockIdx.x) { prm.dbg[blockIdx.x * 16 + 13] = ncoll; prm.dbg[blockIdx.x * 16 + 15] = nsel; prm.dbg[blockIdx.x * 16 + 14] = dbg_outer | (dbg_inner << 8) | (dbg_reload << 16) | (static_cast<long long>(dbg_nitb) << 24); }
+            if (tid == 0 && prm.dbg && qi == block_id) { prm.dbg[block_id * 16 + 13] = ncoll; prm.dbg[block_id * 16 + 15] = nsel; prm.dbg[block_id * 16 + 14] = dbg_outer | (dbg_inner << 8) | (dbg_reload << 16) | (static_cast<long long>(dbg_nitb) << 24); }
 #endif
             if (ncoll > kLzCollMax || s_bad) {
                 overflow = true;
@@ -538,13 +541,20 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
             if (!overflow && tid == 0) prm.out_count[qi] = nout;
         }
         if (overflow) {
+            // This query does not fit the bounded select (or one of its (score, bin) groups would be a treeified bin): it is
+            // handed to the full select — route_select_kernel in list mode right behind this kernel (fspann_route_dev), or the
+            // workgroup that refines this query in the next tick (tick.hip.h).  Until then its count says PENDING.
+            // (Running the full select right here, inlined or as a call, costs this kernel scratch memory: measured 2x slower.)
             if (prm.probe_G > 0) {   // the full select reads the probe lists from global memory: hand this query's over
                 for (int i = tid; i < TP; i += nthreads) probe_in[qi * TP + i] = plist[i];
                 for (int i = tid; i < TD; i += nthreads) nprobe_in[qi * TD + i] = nprobe_l[i];
             }
-            if (tid == 0) prm.ovf_list[atomicAdd(prm.ovf_count, 1)] = static_cast<int32_t>(qi);
+            if (tid == 0) {
+                prm.out_count[qi] = kRoutePending;
+                prm.ovf_list[atomicAdd(prm.ovf_count, 1)] = static_cast<int32_t>(qi);
+            }
         }
-        if (qi + gridDim.x >= prm.nq) {   // last query of this workgroup: nothing to tidy up, the stores drain on their own
+        if (qi + q_stride >= prm.nq) {   // last query of this workgroup: nothing to tidy up, the stores drain on their own
             LZ_STAMP(6);
             LZ_STAMP(7);
             break;
@@ -560,6 +570,12 @@ __global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RoutePar
 #undef LZ_STAMP
 #undef LZ_FOR_TUPLES
 #undef LZ_INSERT
+}
+
+template <int kThreads>
+__global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RouteParams prm) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    route_lazy_run<kThreads>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
 }
 
 }  // namespace fspann

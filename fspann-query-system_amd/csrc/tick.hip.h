@@ -1,0 +1,116 @@
+// tick.hip.h — one launch for three independent stages of three consecutive batches:
+//
+//     encode(batch t+2)   TokenGen coding            (encode_exact_block,   encode.hip.h)
+//     route (batch t+1)   bounded select, probe fused (route_lazy_run,       route_lazy.hip.h)
+//     refine(batch t)     L2 scan + top-K             (refine_scan_block,    refine.hip.h)
+//
+// Why: run one after the other, the three kernels leave the GPU mostly idle — Route is a ~30 us chain of dependent L2
+// round trips per query with all queries resident at once (latency bound, HBM nearly idle), Refine streams 134 MB
+// (bandwidth bound, the integer pipes idle), encode fills a quarter of the CUs.  The stages of ONE batch depend on each
+// other, but a serving loop has batches in flight anyway (in production the host decrypts batch t's candidates while the
+// GPU routes batch t+1), and stages of DIFFERENT batches are independent: each workgroup of this launch takes one role,
+// roles are interleaved over the grid so every CU holds a mix, and the latency-bound workgroups run under the
+// bandwidth-bound ones.  Nothing inside the launch waits for anything else in it (no spin, no grid sync): every
+// workgroup runs to completion on its own, the dependencies are between LAUNCHES (stream order).
+//
+// A query the bounded select cannot hold (count = PENDING, probe lists in the hand-over buffer that travels with the
+// batch) is redone with the full select by the workgroup that refines it one tick later — before it scans.  That removes
+// the hand-back launch of fspann_route_dev (an empty dependent kernel costs ~4.5 us on this runtime).
+#pragma once
+#include "encode.hip.h"
+#include "refine.hip.h"
+#include "route_lazy.hip.h"
+
+namespace fspann {
+
+constexpr int kTickThreads = 256;
+static_assert(kTickThreads == kLzThreads && kTickThreads == kRefRows && kTickThreads == kEncThreads, "one workgroup shape for all roles");
+constexpr int kTickEncQB = 4;
+
+// Each role's arguments are a kernel parameter of their own (one big by-value struct gets copied to scratch memory, and a
+// kernel that needs scratch pays for its allocation at every dispatch).
+struct TickHead {
+    int n_enc, n_route, n_refine;   // workgroups per role (n_enc = enc_gx * enc_gy)
+    int enc_gx;
+    int route_front;                // the first route_front workgroups of the launch are route: the long jobs start first
+    int has_fix;                    // `fix` is valid: PENDING queries of the batch being refined are redone before their scan
+    int64_t nq_refine;              // queries of the batch being refined (n_refine workgroups share them)
+    long long* dbg;                 // FSPANN_DEBUG_STAMPS builds: [grid][4] = {role, index, start, end} (wall_clock64), else unused
+};
+// route = bounded select of the batch being routed; fix_dev = Route of the batch being REFINED (kLds = false arenas, one
+// slice per refine workgroup), in device memory; ref = the scan.
+
+enum { kTickEncode = 0, kTickRoute = 1, kTickRefine = 2 };
+
+// Role and index-within-role of workgroup b.  Dispatch order = grid order, so the order is the schedule: longest jobs
+// first.  The encode workgroups head the grid (each walks the whole alpha matrix through ~16 dependent load rounds: 12 us
+// on an idle memory system, 45 us measured when they start among bandwidth-bound neighbours), then a route-only stretch
+// (30 us chains), then the rest of the route workgroups spread evenly between the refine ones (22 us, bandwidth bound), so
+// that the tail of the launch consists of the short jobs.  (Bresenham line: exact counts, no table.)
+__device__ __forceinline__ void tick_role(const TickHead& p, const int b, int* role, int* idx) {
+    if (b < p.n_enc) { *role = kTickEncode; *idx = b; return; }
+    const int b1 = b - p.n_enc;
+    if (b1 < p.route_front) { *role = kTickRoute; *idx = b1; return; }
+    const long long j = b1 - p.route_front;
+    const long long rr = p.n_route - p.route_front;
+    const long long M = rr + p.n_refine;
+    const long long r0 = (j * rr) / M, r1 = ((j + 1) * rr) / M;
+    if (r1 > r0) { *role = kTickRoute; *idx = p.route_front + static_cast<int>(r0); return; }
+    *role = kTickRefine;
+    *idx = static_cast<int>(j - r0);
+}
+
+template <bool GATHER>
+__global__ __launch_bounds__(kTickThreads, 4) void tick_kernel(const TickHead h, const EncodeArgs<float> enc, const RouteParams route,
+                                                               const RouteParams* __restrict__ fix_dev, const RefineArgs<float, float> ref) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int role, idx;
+    tick_role(h, static_cast<int>(blockIdx.x), &role, &idx);    // block-uniform
+#ifdef FSPANN_DEBUG_STAMPS
+    if (h.dbg && threadIdx.x == 0) { h.dbg[blockIdx.x * 4 + 0] = role; h.dbg[blockIdx.x * 4 + 1] = idx; h.dbg[blockIdx.x * 4 + 2] = wall_clock64(); }
+#endif
+    if (role == kTickRoute) {
+#ifndef TICK_NO_ROUTE
+        route_lazy_run<kLzThreads>(route, smem, idx, h.n_route, idx);
+#endif
+    } else if (role == kTickRefine) {
+        // the scan as a stream (refine_stream_run): this workgroup walks the queries idx, idx + n_refine, ... with the row
+        // loads of the next two tiles always in flight.  First, before any tile is in LDS: queries of its share that the
+        // bounded select handed over one tick ago (count = PENDING) get their Route finished by the full select.
+#ifndef TICK_NO_FIX
+        if (h.has_fix) {
+            for (int64_t qi = idx; qi < h.nq_refine; qi += h.n_refine) {
+                if (ref.cand_count[qi] != kRoutePending) continue;       // block-uniform
+                // the redo's parameters are read from device memory HERE, in the rare path: as a second RouteParams kernel
+                // argument they would sit in ~80 SGPRs for every role
+                const RouteParams fix = *fix_dev;
+                const int TP = fix.TD * fix.P;
+                route_select_query<false, kTickThreads>(fix, smem, idx, fix.probe_g + qi * TP, fix.nprobe_g + qi * fix.TD, qi);
+            }
+            __threadfence();
+            __syncthreads();                                      // F_q and the counts are in global memory, LDS is free again
+        }
+#endif
+        refine_stream_run<float, float, 32, GATHER>(ref, smem, idx, h.n_refine, h.nq_refine, h.has_fix != 0);
+    } else {
+#ifndef TICK_NO_ENC
+        encode_exact_block<float, kTickEncQB>(enc, idx % h.enc_gx, idx / h.enc_gx, reinterpret_cast<int32_t*>(smem));
+#endif
+    }
+#ifdef FSPANN_DEBUG_STAMPS
+    __syncthreads();
+    if (h.dbg && threadIdx.x == 0) h.dbg[blockIdx.x * 4 + 3] = wall_clock64();
+#endif
+}
+
+// The same redo as its own launch (fspann_tick_dev when the three roles cannot share one kernel): a workgroup per query,
+// all but the PENDING ones leave at once.
+__global__ __launch_bounds__(kTickThreads, 4) void tick_fix_kernel(RouteParams fix) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t qi = blockIdx.x;
+    if (fix.out_count[qi] != kRoutePending) return;
+    const int TP = fix.TD * fix.P;
+    route_select_query<false, kTickThreads>(fix, smem, static_cast<int>(blockIdx.x), fix.probe_g + qi * TP, fix.nprobe_g + qi * fix.TD, qi);
+}
+
+}  // namespace fspann

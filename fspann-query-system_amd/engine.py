@@ -296,6 +296,38 @@ class FspannContext:
                                                out_count_ptr, scored_ptr or None, sel_ids_ptr or None, sel_count_ptr or None,
                                                bad_ptr or None))
 
+    def route_handover_bytes(self, nq, probe_override=-1) -> int:
+        return int(self.L.fspann_route_handover_bytes(self._h, nq, probe_override))
+
+    def tick_dev(self, encode=None, route=None, refine=None):
+        """One launch for encode / Route / Refine of three batches in flight (fspann_tick_dev).  Each part is a dict of
+        device pointers (ints) or None:
+          encode: nq, q, codes, [dtype = F32], [bad]
+          route:  nq, codes, limit, ids, count, [probe_override], [handover]
+          refine: nq, q, B, ids, count, k, out_ids, out_dist, out_count, [cand (None: from the store)], [q_dtype], [cand_dtype],
+                  [codes + handover of that batch], [probe_override], [scored]"""
+        t = N.Tick()
+        if encode:
+            t.nq_encode, t.enc_q_dev, t.enc_dtype = encode["nq"], encode["q"], encode.get("dtype", N.F32)
+            t.enc_codes_dev, t.enc_bad_dev = encode["codes"], encode.get("bad") or None
+        if route:
+            t.nq_route, t.route_codes_dev, t.route_limit = route["nq"], route["codes"], route["limit"]
+            t.route_probe_override = route.get("probe_override", -1)
+            t.route_ids_dev, t.route_count_dev, t.route_handover_dev = route["ids"], route["count"], route.get("handover") or None
+        if refine:
+            t.nq_refine, t.ref_q_dev, t.ref_B, t.k = refine["nq"], refine["q"], refine["B"], refine["k"]
+            t.ref_q_dtype, t.ref_cand_dtype = refine.get("q_dtype", N.F32), refine.get("cand_dtype", N.F32)
+            t.ref_cand_dev = refine.get("cand") or None
+            t.ref_ids_dev, t.ref_count_dev = refine["ids"], refine["count"]
+            t.ref_codes_dev, t.ref_handover_dev = refine.get("codes") or None, refine.get("handover") or None
+            t.ref_probe_override = refine.get("probe_override", -1)
+            t.out_ids_dev, t.out_dist_dev, t.out_count_dev = refine["out_ids"], refine["out_dist"], refine["out_count"]
+            t.scored_dev = refine.get("scored") or None
+        N.check(self.L.fspann_tick_dev(self._h, C.byref(t)))
+
+    def last_tick_fused(self) -> bool:
+        return bool(self.L.fspann_last_tick_fused(self._h))
+
     def refine_timing_begin(self, max_launches, every=1):
         N.check(self.L.fspann_refine_timing_begin(self._h, int(max_launches), int(every)))
 

@@ -225,6 +225,58 @@ int fspann_search_store_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int 
                             int32_t* sel_ids_dev, int32_t* sel_count_dev, int32_t* bad_dev);
 const void* fspann_store_dev_ptr(fspann_ctx* ctx, int* dtype);
 
+/* ---- one launch for three stages of three batches in flight --------------------------------------------------------------
+ * The stages of ONE batch depend on each other (QSI:101-352 runs them in sequence), but a serving loop keeps batches in
+ * flight — in production the host loads + decrypts batch t's candidates (PIS:717-724, AesGcmCryptoService.java:126-166)
+ * while the GPU already routes batch t+1 — and stages of DIFFERENT batches are independent.  fspann_tick_dev enqueues, as
+ * ONE kernel whose workgroups each take one role,
+ *     encode of one batch   (= fspann_encode_dev, exact fp64 coding),
+ *     Route of another      (= fspann_route_dev with limit = cap = B, no counters: stage A + A.5, F_q),
+ *     Refine of a third     (= fspann_refine_dev, or fspann_refine_store_dev when ref_cand_dev is NULL),
+ * so that the latency-bound Route workgroups run under the bandwidth-bound Refine ones.  Each part is optional (nq = 0)
+ * and produces exactly what its stand-alone call produces; dependencies between the parts of one batch are the caller's
+ * (stream order between calls: encode in tick t, route in t+1, refine in t+2 or later).  When a part does not qualify for
+ * the shared kernel (fp64 inputs, B > 256, bounded select not legal: see fspann_set_route_mode) the call falls back to the
+ * stand-alone kernels in stream order — same results.
+ * Hand-over buffer: a query the bounded select cannot hold is finished by the full select.  With route_handover_dev = NULL
+ * that happens in a second small launch inside this call.  With a buffer of fspann_route_handover_bytes() that travels
+ * with the batch (same pointer as ref_handover_dev when that batch is refined, together with its codes), the workgroup
+ * that refines the query finishes its Route first: no extra launch.                                                       */
+typedef struct fspann_tick {
+    /* encode role */
+    int64_t nq_encode;
+    const void* enc_q_dev;            /* [nq_encode][dim] */
+    int32_t enc_dtype, pad0;
+    uint64_t* enc_codes_dev;          /* [nq_encode][T*D][W] */
+    int32_t* enc_bad_dev;             /* [nq_encode], 1 where NaN/Inf (may be NULL) */
+    /* route role */
+    int64_t nq_route;
+    const uint64_t* route_codes_dev;
+    int32_t route_probe_override, route_limit;   /* route_limit = B of the Refine that will consume F_q (also its row pitch) */
+    int32_t* route_ids_dev;           /* [nq_route][route_limit] */
+    int32_t* route_count_dev;         /* [nq_route] */
+    void* route_handover_dev;         /* fspann_route_handover_bytes(), or NULL */
+    /* refine role */
+    int64_t nq_refine;
+    const void* ref_q_dev;
+    int32_t ref_q_dtype, ref_cand_dtype;
+    const void* ref_cand_dev;         /* [nq_refine][B][dim] decrypted rows, or NULL: rows read from the resident store by id */
+    int64_t ref_B;
+    int32_t* ref_ids_dev;             /* F_q of that batch, [nq_refine][B] (written when a PENDING query is finished here) */
+    int32_t* ref_count_dev;           /* [nq_refine] */
+    const uint64_t* ref_codes_dev;    /* codes of that batch + the hand-over buffer its Route wrote (both NULL: none PENDING) */
+    void* ref_handover_dev;
+    int32_t ref_probe_override, k;
+    int32_t* out_ids_dev;             /* [nq_refine][k] */
+    double* out_dist_dev;
+    int32_t* out_count_dev;
+    int32_t* scored_dev;              /* may be NULL */
+} fspann_tick;
+size_t fspann_route_handover_bytes(fspann_ctx* ctx, int64_t nq, int probe_override);
+int fspann_tick_dev(fspann_ctx* ctx, const fspann_tick* t);
+/* 1 if the last fspann_tick_dev ran as one shared kernel, 0 if it fell back to the stand-alone kernels. */
+int fspann_last_tick_fused(fspann_ctx* ctx);
+
 /* ---- multi-GPU merge ---------------------------------------------------------
  * The reference is a single JVM with a serial query loop (ForwardSecureANNSystem.java:636): it has no collective.  Here
  * queries shard over GPUs (one context per GPU, index replicated, contiguous equal shards of the batch) and the ONLY
