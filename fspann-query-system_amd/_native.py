@@ -143,6 +143,24 @@ _SIGS = {
     "fspann_route_handover_bytes": (_sz, [_vp, _i64, _i]),
     "fspann_tick_dev": (_i, [_vp, C.POINTER(Tick)]),
     "fspann_last_tick_fused": (_i, [_vp]),
+    "fspann_pointstore_create": (_i, [_i64, _i, C.POINTER(_vp)]),
+    "fspann_pointstore_destroy": (None, [_vp]),
+    "fspann_pointstore_set_master_key": (_i, [_vp, _vp]),
+    "fspann_pointstore_current_version": (_i, [_vp]),
+    "fspann_pointstore_rotate": (_i, [_vp, C.POINTER(_i)]),
+    "fspann_pointstore_retire": (_i, [_vp, _i]),
+    "fspann_pointstore_encrypt": (_i, [_vp, _i64, _i64, _vp, _i, _i]),
+    "fspann_pointstore_delete": (_i, [_vp, _i64]),
+    "fspann_pointstore_reencrypt": (_i, [_vp, _vp, _i64, _i, C.POINTER(_i64)]),
+    "fspann_pointstore_open_batch": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i]),
+    "fspann_pointstore_get_record": (_i, [_vp, _i64, C.POINTER(_i32), _vp, _vp]),
+    "fspann_pointstore_put_record": (_i, [_vp, _i64, _i32, _vp, _vp]),
+    "fspann_pointstore_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "fspann_pipeline_create": (_i, [_vp, _vp, _i64, _i64, _i, _i, C.POINTER(_vp)]),
+    "fspann_pipeline_submit": (_i, [_vp, _i64, _vp, C.POINTER(C.c_uint64)]),
+    "fspann_pipeline_collect": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(_i64), _vp, _vp, _vp]),
+    "fspann_pipeline_stats": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "fspann_pipeline_destroy": (None, [_vp]),
     "fspann_topk_bytes": (_sz, [_i64, _i]),
     "fspann_topk_dist_offset": (_sz, [_i64, _i]),
     "fspann_comm_available": (_i, []),

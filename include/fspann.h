@@ -277,6 +277,46 @@ int fspann_tick_dev(fspann_ctx* ctx, const fspann_tick* t);
 /* 1 if the last fspann_tick_dev ran as one shared kernel, 0 if it fell back to the stand-alone kernels. */
 int fspann_last_tick_fused(fspann_ctx* ctx);
 
+/* ---- host candidate pipeline -------------------------------------------------------------------
+ * QSI stage B's host half at batch scale: for every id of F_q the reference does loadPointIfActive (one RocksDB get + one
+ * Java-deserialised .point file, PIS:717-724, common/RocksDBMetadataManager.java:530-544) and decryptFromPoint
+ * (Cipher.getInstance + AES-256-GCM open + big-endian fp64 decode, crypto/AesGcmCryptoService.java:126-166,261-277) —
+ * 89-93 % of its latency.  Here: ONE packed in-memory point store (record = key version, 12-byte IV, 8*dim-byte big-endian
+ * fp64 ciphertext || 16-byte tag), AES-GCM opened by a thread pool straight into pinned [nq][B][dim] staging, and a
+ * three-stage pipeline (Route of batch i+1 | decrypt of batch i | H2D + Refine of batch i-1).  Crypto is the reference's, bit
+ * for bit: AAD "id:%s|v:%d|d:%d" with the decimal id (common/EncryptedPoint.java:80-83), K_v = HMAC-SHA256(K_M, int32_be(v))
+ * (keymanagement/KeyManager.java:221-237), Migrate = open with the record's version, seal with the current one under a
+ * fresh IV (keymanagement/KeyRotationServiceImpl.java:215-289) — records sealed by a JVM can be imported and read, and vice
+ * versa.  A JVM deployment keeps its own decrypt loop and hands rows to fspann_refine[_dev]; this is the native alternative.
+ * libcrypto (OpenSSL 3) is bound at run time ($FSPANN_CRYPTO_LIB, else libcrypto.so.3).  Decrypt stays on the HOST.        */
+typedef struct fspann_pointstore fspann_pointstore;
+typedef struct fspann_pipeline fspann_pipeline;
+int fspann_pointstore_create(int64_t n, int dim, fspann_pointstore** out);
+void fspann_pointstore_destroy(fspann_pointstore* ps);
+int fspann_pointstore_set_master_key(fspann_pointstore* ps, const uint8_t* key32);
+int fspann_pointstore_current_version(fspann_pointstore* ps);
+int fspann_pointstore_rotate(fspann_pointstore* ps, int* new_version);              /* KeyRotationServiceImpl.rotateKeyOnly :292-305 */
+int fspann_pointstore_retire(fspann_pointstore* ps, int version);                   /* KeyManager retire :274-317 */
+/* encryptToPoint (AesGcmCryptoService.java:55-112) of handles [h0, h0 + cnt): row i of `vectors` = handle h0 + i. */
+int fspann_pointstore_encrypt(fspann_pointstore* ps, int64_t h0, int64_t cnt, const void* vectors, int dtype, int threads);
+int fspann_pointstore_delete(fspann_pointstore* ps, int64_t h);
+/* reencryptTouched: records older than the current version move to it; *reencrypted = how many did. */
+int fspann_pointstore_reencrypt(fspann_pointstore* ps, const int32_t* handles, int64_t cnt, int threads, int64_t* reencrypted);
+/* Stage B for a batch: ids [nq][B], count [nq] (negative = 0) -> dst [nq][B][dim] (dst_dtype), rows that fail to load or
+ * open are skipped and the survivors packed to the front in F_q order (QSI:240-270); out_ids [nq][B], out_count [nq].   */
+int fspann_pointstore_open_batch(fspann_pointstore* ps, int64_t nq, int64_t B, const int32_t* ids, const int32_t* count, void* dst, int dst_dtype,
+                                 int32_t* out_ids, int32_t* out_count, int threads);
+int fspann_pointstore_get_record(fspann_pointstore* ps, int64_t h, int32_t* version, uint8_t* iv12, uint8_t* ct /* 8*dim + 16 */);
+int fspann_pointstore_put_record(fspann_pointstore* ps, int64_t h, int32_t version, const uint8_t* iv12, const uint8_t* ct);
+int fspann_pointstore_stats(fspann_pointstore* ps, int64_t* opened, int64_t* failed);
+/* The pipeline over one (finalized) context: submit host fp32 query batches, collect results in submission order.
+ * Four batches may be in flight; submit blocks when all slots are taken, collect blocks until the oldest batch is done. */
+int fspann_pipeline_create(fspann_ctx* ctx, fspann_pointstore* ps, int64_t nq_max, int64_t B, int k, int host_threads, fspann_pipeline** out);
+int fspann_pipeline_submit(fspann_pipeline* p, int64_t nq, const float* q_host, uint64_t* ticket);
+int fspann_pipeline_collect(fspann_pipeline* p, uint64_t* ticket, int64_t* nq, int32_t* out_ids, double* out_dist, int32_t* out_count);
+int fspann_pipeline_stats(fspann_pipeline* p, double* route_ms, double* decrypt_ms, double* refine_ms, int64_t* batches);
+void fspann_pipeline_destroy(fspann_pipeline* p);
+
 /* ---- multi-GPU merge ---------------------------------------------------------
  * The reference is a single JVM with a serial query loop (ForwardSecureANNSystem.java:636): it has no collective.  Here
  * queries shard over GPUs (one context per GPU, index replicated, contiguous equal shards of the batch) and the ONLY
