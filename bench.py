@@ -15,7 +15,7 @@ loadPointIfActive + AES-GCM decrypt loop hands over in production — are alread
 starts (`--candidates dense`; packed once, before the timed region, for each of the `--query-batches` distinct batches,
 so consecutive steps read DIFFERENT blocks: 32 x 134 MB = 4.3 GB cycled, far beyond the 256 MiB Infinity Cache).
 Beside it (extra objects, never `value`): the trusted-HBM variant where Refine reads plaintext rows of a resident store
-by id (`variants.store`), the gather-inclusive variant, two contexts alternating (`pipelined`), the refine scan on an
+by id (`variants.store`), the gather-inclusive variant, the single-stream and single-kernel pipelines, the refine scan on an
 8 M-row store and at config #4's shape (`roofline.hbm_proof`, `roofline.cfg4_shape`), recall@10 / distance ratio vs
 exact kNN, and the CPU oracle on this box's host cores (`cpu_baseline`).  Rank 0 prints ONE JSON line.
 """
@@ -124,10 +124,14 @@ def main():
                     help="weak: --batch queries per GPU per step; strong: ONE batch of the workload's size cut into contiguous shards")
     ap.add_argument("--merge", default="inline", choices=["inline", "off"], help="N > 1: all-gather of the top-k behind Refine, same stream")
     ap.add_argument("--route-counters", action="store_true", help="also produce lastCandKept / rawSeen (forces the full select)")
-    ap.add_argument("--pipeline", default="serial", choices=["tick", "serial"],
-                    help="tick (value): three batches in flight, one launch per step = encode of batch t+2, Route of batch t+1 and "
-                         "Refine of batch t as ONE kernel (fspann_tick_dev); every step still does one encode, one Route and one "
-                         "Refine of a full batch.  serial: the three stages of ONE batch as three kernels, one after the other")
+    ap.add_argument("--host-threads", type=int, default=16, help="host threads of the end-to-end pipeline's AES-GCM pool (0: every core this process may use)")
+    ap.add_argument("--contexts", type=int, default=3, help="contexts (each with its own HIP stream) per GPU for --pipeline concurrent")
+    ap.add_argument("--pipeline", default="concurrent", choices=["concurrent", "serial", "tick"],
+                    help="concurrent (value): --contexts independent contexts per GPU take the batches in turn, each running encode -> "
+                         "Route -> Refine of ITS batch as three kernels on its own HIP stream; the hardware queues overlap the "
+                         "latency-bound Route of one batch with the bandwidth-bound Refine of another.  serial: one context, one stream "
+                         "(latency of a single batch, nothing overlaps).  tick: one stream, three batches in flight, encode(t+2) + "
+                         "Route(t+1) + Refine(t) as ONE kernel (fspann_tick_dev)")
     args = ap.parse_args()
 
     # Only the final JSON line may reach stdout: libraries (RCCL prints a version banner) write to fd 1 too.
@@ -187,7 +191,8 @@ def main():
     ctx.build_index(X)                                      # GPU coding (MFMA pre-filter + exact re-check) + partition cut
     ctx.store_set(X)                                        # plaintext rows: source of the dense blocks / the store variant
     ctxs = [ctx]
-    if extras:                                              # second context (own HIP stream) for the `pipelined` extra
+    nctx = max(1, args.contexts) if args.pipeline == "concurrent" else 1
+    for _ in range(nctx - 1):                               # further contexts (own HIP streams) over the same frozen index
         c2 = pkg.FspannContext(cfg, local_rank)
         c2.set_gfunctions(*ctx.get_gfunctions())
         c2.set_id_meta(n)
@@ -245,19 +250,22 @@ def main():
         if ctx.unmodelled_queries() != 0:
             raise SystemExit("bench: a query's HashMap would have treeified a bin at this workload (Java order not modelled)")
 
-    comm = None
+    comms = None
     gather_path = None
     if use_dist and args.merge != "off":
-        comm = fdist.LibComm(ctx, world, rank, dev)        # fspann_comm_* of the C library, bootstrapped over the torch group
-        gather_path = (f"fspann_allgather_topk_dev (ncclAllGather via {os.path.basename(comm.library)}) on the context's stream"
-                       if comm.ok else "torch.distributed all_gather_into_tensor")
+        # fspann_comm_* of the C library: one communicator per context (its all-gathers run on that context's stream),
+        # bootstrapped over the torch group; all ranks fall back to torch.distributed together if any of them cannot
+        comms = [fdist.LibComm(c_, world, rank, dev) for c_ in ctxs]
+        lib_ok = all(cm.ok for cm in comms)
+        gather_path = (f"fspann_allgather_topk_dev (ncclAllGather via {os.path.basename(comms[0].library)}) on each context's stream"
+                       if lib_ok else "torch.distributed all_gather_into_tensor")
 
-    def merge(b, par, stream):
+    def merge(b, par, stream, si=0):
         """the ONE collective of the path, behind Refine on the same stream"""
-        if comm is None:
+        if comms is None:
             return
-        if comm.ok:
-            comm.allgather_topk(b["topk"][par], b["gathered"][par])
+        if comms[si].ok:
+            comms[si].allgather_topk(b["topk"][par], b["gathered"][par])
         else:
             with torch.cuda.stream(stream):
                 fdist.allgather_topk(b["topk"][par], b["gathered"][par])
@@ -282,7 +290,7 @@ def main():
             for pov in probe_passes:
                 cx.search_store_dev(Q, qp, F32, pov, B, k, tk.ids.data_ptr(), tk.dist.data_ptr(), b["out_cnt"].data_ptr(),
                                     b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), b["bad"].data_ptr())
-            merge(b, par, stream)
+            merge(b, par, stream, si)
             return
         for pov in probe_passes[:-1]:   # first pass of the adaptive retry (see probe_passes); the stages below are the last pass
             cx.search_store_dev(Q, qp, F32, pov, B, k, tk.ids.data_ptr(), tk.dist.data_ptr(), b["out_cnt"].data_ptr(),
@@ -311,7 +319,7 @@ def main():
                           b["out_cnt"].data_ptr(), b["scored"].data_ptr())
         if events is not None:
             events[4].record(stream)
-        merge(b, par, stream)
+        merge(b, par, stream, si)
 
     def tick(mode, unfused=False):
         """One step of the 3-deep pipeline on context 0: encode(batch t+2), Route(batch t+1), Refine(batch t) — ONE launch.
@@ -382,8 +390,13 @@ def main():
         if use_dist:
             dist.barrier()
 
-    def timed(mode, steps, warmup, with_events=False):
-        """(elapsed seconds of `steps` steps, max over ranks; kernel-attached refine timing when asked)"""
+    def timed(mode, steps, warmup, nact=1, with_events=False):
+        """`steps` steps over `nact` contexts taking the batches in turn: (elapsed seconds, max over ranks; (dispatches, ms) of the
+        refinement-scan launches that carried kernel-attached events; their spacing).  With one context every `every`-th scan
+        dispatch carries the events.  With several, kernels of different contexts overlap, so for a SOLO reading every
+        `every`-th step first drains all contexts and then runs alone, its scan dispatch carrying the events — inside the
+        timed region, and paid for by it."""
+        active[0] = nact
         for b_ in bufs:
             b_["nsteps"] = 0
         step_no[0] = 0
@@ -391,13 +404,22 @@ def main():
             step(mode)
         barrier()
         every = max(2, steps // 8)                      # about eight timed dispatches whatever --steps is
-        if with_events:
-            for c_ in ctxs[:active[0]]:
-                c_.refine_timing_begin(steps, every)
+        solo_n, solo_ms = 0, 0.0
+        if with_events and nact == 1:
+            ctxs[0].refine_timing_begin(steps, every)
         t_s = time.perf_counter()
-        for _ in range(steps):
-            step(mode)
-        for c_ in ctxs[:active[0]]:
+        for i in range(steps):
+            if with_events and nact > 1 and (i % every) == every - 1:
+                for c_ in ctxs[:nact]:
+                    c_.sync()
+                cs = ctxs[step_no[0] % nact]
+                cs.refine_timing_begin(2, 1)
+                step(mode)
+                n_, ms_ = cs.refine_timing_end()
+                solo_n, solo_ms = solo_n + n_, solo_ms + ms_
+            else:
+                step(mode)
+        for c_ in ctxs[:nact]:
             c_.sync()
         torch.cuda.synchronize()
         if use_dist:
@@ -407,7 +429,10 @@ def main():
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
-        rt = [c_.refine_timing_end() for c_ in ctxs[:active[0]]] if with_events else None
+        rt = None
+        if with_events:
+            rt = [ctxs[0].refine_timing_end()] if nact == 1 else [(solo_n, solo_ms)]
+        active[0] = 1
         return el, rt, every
 
     # ---------------- the timed region ------------------------------------------------------------------------------------
@@ -417,7 +442,7 @@ def main():
         elapsed, rt, TIMED_EVERY = timed_tick(mode, args.steps, args.warmup, with_events=True)
         tick_fused = ctx.last_tick_fused()
     else:
-        elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, with_events=True)
+        elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, nact=nctx, with_events=True)
         tick_fused = False
     ref_launches = sum(x for x, _ in rt)
     ref_ms = sum(t for _, t in rt) / max(1, ref_launches)          # kernel-attached HIP events, on the context's stream
@@ -436,13 +461,19 @@ def main():
     st_mean = stage_ms.mean(axis=0)
 
     # ---------------- extra passes (N = 1; reported beside `value`, never as it) -------------------------------------------
-    variants, pipelined, hbm_proof, cfg4_shape, peak_measured = {}, None, None, None, None
+    variants, hbm_proof, cfg4_shape, peak_measured = {}, None, None, None
     if extras:
-        if use_tick:
+        if use_tick or nctx > 1:
             el_s, _, _ = timed(mode, args.steps, max(2, args.warmup))
             variants["serial"] = dict(value=round(Q * args.steps / el_s, 1), unit="queries/s", ms_per_step=round(el_s * 1000.0 / args.steps, 4),
-                                      note="the three stages of ONE batch as three kernels one after the other (encode, Route, Refine): latency of a "
-                                           "single batch; nothing overlaps")
+                                      note="ONE context, one stream: the three stages of one batch as three kernels one after the other (encode, Route, "
+                                           "Refine); nothing overlaps")
+        if mode in ("dense", "store") and len(probe_passes) == 1 and not args.route_counters and not use_tick:
+            el_t, _, _ = timed_tick(mode, args.steps, max(2, args.warmup))
+            variants["tick"] = dict(value=round(Q * args.steps / el_t, 1), unit="queries/s", ms_per_step=round(el_t * 1000.0 / args.steps, 4),
+                                    fused=bool(ctx.last_tick_fused()),
+                                    note="ONE stream, three batches in flight: encode(t+2) + Route(t+1) + Refine(t) as one kernel (fspann_tick_dev)")
+        if use_tick:
             other = "store" if mode == "dense" else "dense"
             el_o, _, _ = timed_tick(other, args.steps, max(2, args.warmup))
             variants["tick_" + other] = dict(value=round(Q * args.steps / el_o, 1), unit="queries/s", ms_per_step=round(el_o * 1000.0 / args.steps, 4),
@@ -455,14 +486,49 @@ def main():
                          ("dense", "the [Q][B][d] block is resident before the step (SURVEY 8d kernel path)")):
             if vm == mode and not use_tick:
                 continue
-            el_v, _, _ = timed(vm, args.steps, max(2, args.warmup))
+            el_v, _, _ = timed(vm, args.steps, max(2, args.warmup), nact=nctx)
             variants[vm] = dict(value=round(Q * args.steps / el_v, 1), unit="queries/s", ms_per_step=round(el_v * 1000.0 / args.steps, 4), note=note)
-        active[0] = 2
-        el_p, _, _ = timed(mode, args.steps, max(2, args.warmup))
-        active[0] = 1
-        pipelined = dict(streams=2, value=round(Q * args.steps / el_p, 1), unit="queries/s", ms_per_step=round(el_p * 1000.0 / args.steps, 4),
-                         note="same steps alternating between two contexts/HIP streams on this GPU: Route of one batch overlaps Refine of "
-                              "the other; kernel durations are no longer solo, so the roofline is not taken here")
+
+    # ---------------- end to end (N = 1): the native host candidate pipeline — Route on the GPU, AES-256-GCM open of F_q's records
+    # on the host cores into pinned staging, H2D, Refine — three batches in flight (fspann_pipeline_*) ------------
+    end_to_end = None
+    if extras:
+        from fspann_amd import hostpipe
+        try:
+            nthr = len(os.sched_getaffinity(0))
+        except AttributeError:
+            nthr = os.cpu_count() or 1
+        nthr = min(nthr, args.host_threads) if args.host_threads > 0 else nthr
+        with hostpipe.PointStore(n, d) as ps:
+            t_e = time.perf_counter()
+            ps.encrypt(X, threads=nthr)
+            t_e = time.perf_counter() - t_e
+            with hostpipe.Pipeline(ctx, ps, Q, B, k, host_threads=nthr) as pl:
+                nbe = 10
+
+                def run_e2e(nb_):
+                    got = []
+                    for i in range(nb_):
+                        pl.submit(Qall[i % NB])
+                        if pl.in_flight == 4:
+                            got.append(pl.collect())
+                    while pl.in_flight:
+                        got.append(pl.collect())
+                    return got
+                run_e2e(2)
+                t_p = time.perf_counter()
+                got = run_e2e(nbe)
+                t_p = time.perf_counter() - t_p
+                st = pl.stats()
+            e2e_first = got[0]
+        end_to_end = dict(value=round(Q * nbe / t_p, 1), unit="queries/s", batches=nbe, host_threads=nthr,
+                          ms_per_batch=round(t_p * 1000.0 / nbe, 2), stage_ms=dict(route=round(st["route_ms"], 3), decrypt=round(st["decrypt_ms"], 3),
+                                                                                   h2d_refine=round(st["refine_ms"], 3)),
+                          candidate_bytes_per_batch=Q * B * d * 4, records_opened_per_batch=Q * B,
+                          store_encrypt_s=round(t_e, 2),
+                          note="fspann_pipeline: Route (GPU) | AES-256-GCM open of 262 144 records per batch on the host threads into pinned staging | "
+                               "H2D + Refine (GPU), four batches in flight; record format, AAD and key derivation are the reference's "
+                               "(AesGcmCryptoService.java:55-166, EncryptedPoint.java:80-83, KeyManager.java:221-237); host-bound by design")
 
     # one more (untimed) step of batch 0 on context 0: its results are what recall and the CPU baseline are checked on
     for b_ in bufs:
@@ -473,12 +539,16 @@ def main():
         tick_prime()
         tick(mode)
     else:
-        step(mode, batch=0)
+        step(mode, batch=0)   # (active[0] == 1: context 0)
     barrier()
     out_ids, out_dist = bufs[0]["topk"][0].ids, bufs[0]["topk"][0].dist
     got_ids, got_dist = out_ids.cpu().numpy(), out_dist.cpu().numpy()
     if ctx.unmodelled_queries() != 0:
         raise SystemExit("bench: a query's HashMap would have treeified a bin during the run (Java order not modelled)")
+    if end_to_end is not None:      # same batch through the decrypting pipeline: same answer
+        end_to_end["matches_kernel_path"] = bool(np.array_equal(e2e_first["ids"], got_ids) and np.array_equal(e2e_first["dist"], got_dist))
+        if not end_to_end["matches_kernel_path"]:
+            raise SystemExit("bench: the end-to-end pipeline and the kernel path disagree on batch 0")
 
     # ---------------- roofline of the refinement scan (north_star's HBM-bound kernel) ---------------------------------------
     # algorithmic bytes per launch: Q * (B*d*4 + d*4 + k*8)
@@ -517,7 +587,7 @@ def main():
             nl, tms = cp.refine_timing_end()
         del big, rid
         hp_ms = tms / max(1, nl)
-        hbm_proof = dict(kernel="refine_scan_kernel<float,float,32,true,true>", store_rows=NS, store_bytes=NS * d * 4, launches=nl,
+        hbm_proof = dict(kernel="refine_stream_kernel<float,float,32,true>", store_rows=NS, store_bytes=NS * d * 4, launches=nl,
                          avg_launch_ms=round(hp_ms, 5), achieved=round(ref_bytes / (hp_ms * 1e-3) / 1e9, 1),
                          frac=round(ref_bytes / (hp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          note="1024 x 256 uniformly random rows of a 4.1 GB store per launch, 8 id sets cycled: at most 6 % of a launch's rows "
@@ -551,12 +621,12 @@ def main():
             nl4, tms4 = c4.refine_timing_end()
             bytes4 = Q * (B4 * d4 * 4 + d4 * 4 + k * 8)
             scan_ms, call_ms = tms4 / max(1, nl4), e0.elapsed_time(e1) / 12
-            cfg4_shape = dict(kernel="refine_scan_kernel<float,float,32,true,false> x 4 chunks + refine_merge_kernel", Q=Q, B=B4, dim=d4,
+            cfg4_shape = dict(kernel="refine_stream_kernel<float,float,32,false> over 4 chunks per query + refine_merge_kernel", Q=Q, B=B4, dim=d4,
                               algorithmic_bytes_per_launch=bytes4, scan_launch_ms=round(scan_ms, 4), scan_plus_merge_ms=round(call_ms, 4),
                               achieved=round(bytes4 / (scan_ms * 1e-3) / 1e9, 1), frac=round(bytes4 / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               note="two 3.2 GB blocks alternate; events attached to the scan kernel; scan_plus_merge_ms = whole fspann_refine_dev call")
             del cand4
-    kname = "refine_scan_kernel<float,float,32,true,%s>" % ("true" if mode == "store" else "false")
+    kname = "refine_stream_kernel<float,float,32,%s>" % ("true" if mode == "store" else "false")
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, peak_spec=HBM_PEAK_GBS,
                     peak_measured=peak_measured, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     frac_of_measured=round(achieved / peak_measured, 4) if peak_measured else None,
@@ -564,8 +634,11 @@ def main():
                     algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5), launches=ref_launches,
                     working_set_bytes=(NB * Q * B * d * 4) if mode == "dense" else n * d * 4,
                     timing=("every %d-th step of the timed region runs its three stages as stand-alone kernels instead of the shared one; the "
-                            "refine_scan_kernel dispatch of those steps carries HIP start/stop events (hipExtLaunchKernel, on the context's stream)"
-                            if use_tick else "HIP start/stop events attached to every %d-th refine_scan_kernel dispatch of the timed region "
+                            "refinement-scan dispatch of those steps carries HIP start/stop events (hipExtLaunchKernel, on the context's stream)"
+                            if use_tick else ("every %d-th step of the timed region first drains all contexts and then runs alone; its refinement-scan "
+                                              "dispatch carries HIP start/stop events (hipExtLaunchKernel, on its context's stream): a SOLO duration, "
+                                              "measured inside the timed region") if nctx > 1 else
+                            "HIP start/stop events attached to every %d-th refinement-scan dispatch of the timed region "
                             "(hipExtLaunchKernel, on the context's stream)") % TIMED_EVERY,
                     bracket_ms=round(float(st_mean[3]), 5), hbm_proof=hbm_proof, cfg4_shape=cfg4_shape)
 
@@ -682,10 +755,12 @@ def main():
             "config": {"workload": args.workload, "n": n, "dim": d, "tables": T, "divisions": D, "m": m, "lambda": lam,
                        "code_bits": m * lam, "probes": 5, "B": B, "k": k, "queries_per_gpu_per_step": Q, "queries_per_step": q_job,
                        "distinct_query_batches": NB, "route_counters": bool(args.route_counters), "passes_per_step": len(probe_passes),
-                       "parallelism": f"query-sharded x{world}, index replicated", "merge": gather_path, "streams_per_gpu": 1,
+                       "parallelism": f"query-sharded x{world}, index replicated", "merge": gather_path, "streams_per_gpu": nctx,
                        "pipeline": ("tick: 3 batches in flight, one launch per step = encode(t+2) + Route(t+1) + Refine(t) as one kernel (tick_kernel, "
                                     "fused=%s); every step does one full-batch encode, Route and Refine" % tick_fused) if use_tick
-                       else "serial: encode, Route, Refine of one batch as three kernels",
+                       else ("concurrent: %d contexts per GPU take the batches in turn, each running encode -> Route -> Refine of its batch as three "
+                             "kernels on its own HIP stream (hardware queues overlap Route of one batch with Refine of another)" % nctx) if nctx > 1
+                       else "serial: encode, Route, Refine of one batch as three kernels on one stream",
                        "candidates": {"dense": "kernel path (SURVEY 8d): [Q][B][d] blocks of decrypted candidate rows resident in HBM before the timed "
                                                "region (packed once per distinct batch), scanned by refine_scan_kernel",
                                       "store": "trusted-HBM variant: rows read from an HBM-resident plaintext store by id inside the refine scan",
@@ -697,19 +772,19 @@ def main():
             "roofline": roofline,
             "route_stage": route_info,
             "variants": variants or None,
-            "pipelined": pipelined,
+            "end_to_end": end_to_end,
             "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if use_dist and comm is not None and rank == 0:
+    if use_dist and comms is not None and rank == 0:
         # merged result = every rank's top-k in rank order; rank 0's own slice must be intact
         g_ids, g_dist = bufs[0]["gathered"][0].split()
         assert torch.equal(g_ids[:Q], out_ids) and torch.equal(g_dist[:Q], out_dist)
-    if comm is not None:
-        comm.close()
+    for cm in (comms or []):
+        cm.close()
     for c_ in ctxs[::-1]:
         c_.close()
     if use_dist:

@@ -472,10 +472,10 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_lazy_cap = std::max(0, env_int("FSPANN_ROUTE_LAZY_CAP", 0));
         c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
-        c->knob_refine_stream = std::min(4, std::max(0, env_int("FSPANN_REFINE_STREAM", 2)));
+        c->knob_refine_stream = std::min(4, std::max(0, env_int("FSPANN_REFINE_STREAM", 3)));
         c->knob_tick_refine = std::min(4, std::max(1, env_int("FSPANN_TICK_REFINE", 1)));
         c->knob_tick_fuse = env_int("FSPANN_TICK_FUSE", 1) != 0;
-        c->knob_tick_front = std::min(100, std::max(0, env_int("FSPANN_TICK_FRONT", 50)));
+        c->knob_tick_front = std::min(100, std::max(0, env_int("FSPANN_TICK_FRONT", 100)));
     }
     c->h_min.resize(c->TD); c->h_max.resize(c->TD); c->h_off.resize(c->TD); c->h_rep.resize(c->TD); c->h_ids.resize(c->TD);
     c->h_table_set.assign(c->TD, 0);
@@ -1287,7 +1287,7 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
         const size_t arena = ((static_cast<size_t>(pX.sort_cap) * 8 + static_cast<size_t>(plX.ht_size) * 4 + static_cast<size_t>(plX.max_tuples) * 4 +
                                ((static_cast<size_t>(plX.max_tuples) * 2 + 15) & ~size_t(15))) + 255) & ~size_t(255);
         const int64_t gstride = (pX.sort_cap < full_sort) ? full_sort : 0;
-        const int64_t fix_wgs = std::min<int64_t>(t->nq_refine, static_cast<int64_t>(c->num_cus) * c->knob_tick_refine);   // one slice per refine workgroup
+        const int64_t fix_wgs = t->nq_refine;   // one slice per refine workgroup
         const size_t so = static_cast<size_t>(fix_wgs) * gstride * 8;
         if ((rc = ensure(c, c->ws_tickfix, static_cast<size_t>(fix_wgs) * arena + so + 512))) return rc;
         pX.g_sort = so ? static_cast<uint64_t*>(c->ws_tickfix.p) : nullptr;
@@ -1362,8 +1362,7 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
         c->last_route_lazy = 1;
     }
     if (F) {
-        // the scan runs as a stream: a few workgroups per CU, each walking several queries (refine_stream_run)
-        p.n_refine = static_cast<int>(std::min<int64_t>(t->nq_refine, static_cast<int64_t>(c->num_cus) * c->knob_tick_refine));
+        p.n_refine = static_cast<int>(t->nq_refine);          // one workgroup per query (nchunks == 1)
         p.nq_refine = t->nq_refine;
         raT = RefineArgs<float, float>{static_cast<const float*>(t->ref_q_dev), static_cast<const float*>(rows), gather ? c->store_n : 0, t->ref_B, d,
                                          t->ref_ids_dev, t->ref_count_dev, t->k, 1, t->out_ids_dev, t->out_dist_dev, t->out_count_dev, t->scored_dev,
@@ -1609,6 +1608,7 @@ int fspann_pointstore_encrypt(fspann_pointstore* ps, int64_t h0, int64_t cnt, co
         std::atomic<long long> bad{0};
         const int rc = dtype == FSPANN_F32 ? pointstore_encrypt<float>(ps, h0, cnt, static_cast<const float*>(vectors), threads, &bad)
                                            : pointstore_encrypt<double>(ps, h0, cnt, static_cast<const double*>(vectors), threads, &bad);
+        if (rc == -2) return fail(FSPANN_E_DEVICE, "RAND_bytes failed");
         if (rc) return fail(FSPANN_E_STATE, "current key version is not derivable (retired?)");
         if (bad.load()) return fail(FSPANN_E_DEVICE, "AES-GCM seal failed for %lld records", bad.load());
         return FSPANN_OK;
@@ -1624,7 +1624,7 @@ int fspann_pointstore_delete(fspann_pointstore* ps, int64_t h) {
 // sealed again with the current one under a fresh IV (and the new version in the AAD); failures are skipped silently (:274-276).
 int fspann_pointstore_reencrypt(fspann_pointstore* ps, const int32_t* handles, int64_t cnt, int threads, int64_t* reencrypted) {
     if (!ps || (cnt > 0 && !handles)) return fail(FSPANN_E_NULL, "point store / handles is null");
-    if (cnt < 0) return fail(FSPANN_E_ARG, "cnt < 0");
+    if (cnt < 0 || cnt > (1LL << 26)) return fail(FSPANN_E_ARG, "cnt out of range (at most 2^26 handles per call)");
     return guarded([&]() -> int {
         CryptoApi* a = crypto_api();
         const int target = ps->current_version.load();
@@ -1632,8 +1632,11 @@ int fspann_pointstore_reencrypt(fspann_pointstore* ps, const int32_t* handles, i
         if (!ps->key_for(target, tkey)) return fail(FSPANN_E_STATE, "current key version is not derivable");
         std::atomic<long long> done{0};
         const int dim = ps->dim, ptlen = 8 * dim;
+        std::vector<unsigned char> ivs(static_cast<size_t>(cnt) * kIvBytes);     // fresh IVs, one RAND_bytes call on this thread
+        if (cnt > 0 && a->RAND_bytes(ivs.data(), static_cast<int>(std::min<size_t>(ivs.size(), 1u << 30))) != 1) return fail(FSPANN_E_DEVICE, "RAND_bytes failed");
         parallel_blocks(cnt, threads, 256, [&](int, int64_t b, int64_t e) {
             GcmWorker w(a);
+            if (!w.set_enc_key(target, tkey)) return;
             std::vector<unsigned char> scratch(kIvBytes + 16 * static_cast<size_t>(dim) + kTagBytes + 64), pt(ptlen), sealed(ptlen + kTagBytes);
             std::vector<double> row(dim);
             char aad[96];
@@ -1644,10 +1647,9 @@ int fspann_pointstore_reencrypt(fspann_pointstore* ps, const int32_t* handles, i
                 if (!pointstore_open_one(ps, w, h, scratch, row.data(), &oldv)) continue;     // forward-secure skip
                 if (oldv >= target) continue;                                                 // already upgraded
                 for (int j = 0; j < dim; j++) { uint64_t bits; std::memcpy(&bits, &row[j], 8); bits = bswap64(bits); std::memcpy(pt.data() + 8 * j, &bits, 8); }
-                unsigned char iv[kIvBytes];
-                if (a->RAND_bytes(iv, kIvBytes) != 1) continue;
+                const unsigned char* iv = ivs.data() + static_cast<size_t>(i) * kIvBytes;
                 const int al = aad_for(aad, sizeof(aad), h, target, dim);
-                if (!w.seal(tkey, iv, reinterpret_cast<const unsigned char*>(aad), al, pt.data(), ptlen, sealed.data())) continue;
+                if (!w.seal(iv, reinterpret_cast<const unsigned char*>(aad), al, pt.data(), ptlen, sealed.data())) continue;
                 int32_t expect = oldv;
                 if (!ps->ver(h)->compare_exchange_strong(expect, -1, std::memory_order_acq_rel)) continue;   // someone else rewrote it meanwhile
                 unsigned char* r = ps->rec(h);

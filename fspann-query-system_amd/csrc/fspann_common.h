@@ -85,10 +85,10 @@ struct fspann_ctx {
     int knob_lazy_cap = 0;           // FSPANN_ROUTE_LAZY_CAP: entries one query may hold in the bounded select (tests)
     int knob_fused_probe = 1;        // FSPANN_ROUTE_FUSED_PROBE=0: separate probe kernel in front of the bounded select
     int knob_refine_dc = 0;          // FSPANN_REFINE_DC: dims per LDS tile of the refinement scan (tools/refine_bench.py)
-    int knob_refine_stream = 2;      // FSPANN_REFINE_STREAM: workgroups per CU of the streaming refinement scan (0: one workgroup per query)
+    int knob_refine_stream = 3;      // FSPANN_REFINE_STREAM: workgroups per CU of the streaming refinement scan (0: one workgroup per query)
     int knob_tick_refine = 1;        // FSPANN_TICK_REFINE: refine workgroups per CU inside a tick (each streams several queries)
     int knob_tick_fuse = 1;          // FSPANN_TICK_FUSE=0: fspann_tick_dev always uses the stand-alone kernels
-    int knob_tick_front = 50;        // FSPANN_TICK_FRONT: percent of a tick's Route workgroups that head the grid
+    int knob_tick_front = 100;       // FSPANN_TICK_FRONT: percent of a tick's Route workgroups that head the grid
     int last_tick_fused = 0;
 
     // GFunctions: alphaT[dim][P_total] fp64 (transposed for coalescing), r/omega[P_total]

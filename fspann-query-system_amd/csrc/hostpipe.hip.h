@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -77,37 +78,49 @@ constexpr int kIvBytes = 12, kTagBytes = 16;
 
 inline uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
 
-// One reusable cipher context per worker thread (the reference pays Cipher.getInstance per candidate).
+// One pair of reusable cipher contexts per worker thread (the reference pays Cipher.getInstance per candidate).  The cipher is
+// bound to a context ONCE and the key only when the version changes; a record then costs an IV reset + GCM over ~1 KB.
+// (EVP_*Init_ex with the cipher argument re-resolves the implementation on every call in OpenSSL 3: measured 38 us per open.)
 struct GcmWorker {
     CryptoApi* a;
-    void* ctx;
-    explicit GcmWorker(CryptoApi* api) : a(api), ctx(api->CTX_new()) {}
-    ~GcmWorker() { if (ctx) a->CTX_free(ctx); }
+    void* dctx;
+    void* ectx;
+    int dec_version = 0, enc_version = 0;     // key version currently loaded into each context (0: none)
+    bool dec_ready = false, enc_ready = false;
+    explicit GcmWorker(CryptoApi* api) : a(api), dctx(api->CTX_new()), ectx(api->CTX_new()) {
+        dec_ready = dctx && a->DecryptInit_ex(dctx, a->aes_256_gcm(), nullptr, nullptr, nullptr) == 1 && a->CTX_ctrl(dctx, kGcmSetIvLen, kIvBytes, nullptr) == 1;
+        enc_ready = ectx && a->EncryptInit_ex(ectx, a->aes_256_gcm(), nullptr, nullptr, nullptr) == 1 && a->CTX_ctrl(ectx, kGcmSetIvLen, kIvBytes, nullptr) == 1;
+    }
+    ~GcmWorker() { if (dctx) a->CTX_free(dctx); if (ectx) a->CTX_free(ectx); }
     GcmWorker(const GcmWorker&) = delete;
     GcmWorker& operator=(const GcmWorker&) = delete;
-    // ct_tag = ciphertext || tag (javax.crypto doFinal layout).  false = tag mismatch (wrong key, AAD or corrupted record).
-    bool open(const unsigned char* key, const unsigned char* iv, const unsigned char* aad, int aad_len, const unsigned char* ct_tag, int ct_len,
-              unsigned char* pt) {
-        int n = 0;
-        if (a->DecryptInit_ex(ctx, a->aes_256_gcm(), nullptr, nullptr, nullptr) != 1) return false;
-        if (a->CTX_ctrl(ctx, kGcmSetIvLen, kIvBytes, nullptr) != 1) return false;
-        if (a->DecryptInit_ex(ctx, nullptr, nullptr, key, iv) != 1) return false;
-        if (aad_len > 0 && a->DecryptUpdate(ctx, nullptr, &n, aad, aad_len) != 1) return false;
-        if (a->DecryptUpdate(ctx, pt, &n, ct_tag, ct_len) != 1) return false;
-        if (a->CTX_ctrl(ctx, kGcmSetTag, kTagBytes, const_cast<unsigned char*>(ct_tag + ct_len)) != 1) return false;
-        int m = 0;
-        return a->DecryptFinal_ex(ctx, pt + n, &m) == 1;
+    bool set_dec_key(int version, const unsigned char* key) {
+        if (!dec_ready || a->DecryptInit_ex(dctx, nullptr, nullptr, key, nullptr) != 1) { dec_version = 0; return false; }
+        dec_version = version;
+        return true;
     }
-    bool seal(const unsigned char* key, const unsigned char* iv, const unsigned char* aad, int aad_len, const unsigned char* pt, int pt_len,
-              unsigned char* ct_tag) {
+    bool set_enc_key(int version, const unsigned char* key) {
+        if (!enc_ready || a->EncryptInit_ex(ectx, nullptr, nullptr, key, nullptr) != 1) { enc_version = 0; return false; }
+        enc_version = version;
+        return true;
+    }
+    // ct_tag = ciphertext || tag (javax.crypto doFinal layout).  false = tag mismatch (wrong key, AAD or corrupted record).
+    bool open(const unsigned char* iv, const unsigned char* aad, int aad_len, const unsigned char* ct_tag, int ct_len, unsigned char* pt) {
+        int n = 0;
+        if (a->DecryptInit_ex(dctx, nullptr, nullptr, nullptr, iv) != 1) return false;
+        if (aad_len > 0 && a->DecryptUpdate(dctx, nullptr, &n, aad, aad_len) != 1) return false;
+        if (a->DecryptUpdate(dctx, pt, &n, ct_tag, ct_len) != 1) return false;
+        if (a->CTX_ctrl(dctx, kGcmSetTag, kTagBytes, const_cast<unsigned char*>(ct_tag + ct_len)) != 1) return false;
+        int m = 0;
+        return a->DecryptFinal_ex(dctx, pt + n, &m) == 1;
+    }
+    bool seal(const unsigned char* iv, const unsigned char* aad, int aad_len, const unsigned char* pt, int pt_len, unsigned char* ct_tag) {
         int n = 0, m = 0;
-        if (a->EncryptInit_ex(ctx, a->aes_256_gcm(), nullptr, nullptr, nullptr) != 1) return false;
-        if (a->CTX_ctrl(ctx, kGcmSetIvLen, kIvBytes, nullptr) != 1) return false;
-        if (a->EncryptInit_ex(ctx, nullptr, nullptr, key, iv) != 1) return false;
-        if (aad_len > 0 && a->EncryptUpdate(ctx, nullptr, &n, aad, aad_len) != 1) return false;
-        if (a->EncryptUpdate(ctx, ct_tag, &n, pt, pt_len) != 1) return false;
-        if (a->EncryptFinal_ex(ctx, ct_tag + n, &m) != 1) return false;
-        return a->CTX_ctrl(ctx, kGcmGetTag, kTagBytes, ct_tag + pt_len) == 1;
+        if (a->EncryptInit_ex(ectx, nullptr, nullptr, nullptr, iv) != 1) return false;
+        if (aad_len > 0 && a->EncryptUpdate(ectx, nullptr, &n, aad, aad_len) != 1) return false;
+        if (a->EncryptUpdate(ectx, ct_tag, &n, pt, pt_len) != 1) return false;
+        if (a->EncryptFinal_ex(ectx, ct_tag + n, &m) != 1) return false;
+        return a->CTX_ctrl(ectx, kGcmGetTag, kTagBytes, ct_tag + pt_len) == 1;
     }
 };
 
@@ -185,8 +198,16 @@ inline int pointstore_encrypt(fspann_pointstore* ps, int64_t h0, int64_t cnt, co
     unsigned char key[32];
     if (!ps->key_for(v, key)) return -1;
     const int dim = ps->dim, ptlen = 8 * dim;
+    // every IV comes from ONE RAND_bytes call on the calling thread: OpenSSL instantiates a DRBG per thread on first use, and
+    // with short-lived worker threads that instantiation (serialised on the parent DRBG) was 10 s for 1 M records
+    std::vector<unsigned char> ivs(static_cast<size_t>(cnt) * kIvBytes);
+    for (size_t off = 0; off < ivs.size(); off += (1u << 30)) {
+        const int len = static_cast<int>(std::min<size_t>(ivs.size() - off, 1u << 30));
+        if (a->RAND_bytes(ivs.data() + off, len) != 1) return -2;
+    }
     parallel_blocks(cnt, threads, 1024, [&](int, int64_t b, int64_t e) {
         GcmWorker w(a);
+        if (!w.set_enc_key(v, key)) { (*bad) += e - b; return; }
         std::vector<unsigned char> pt(ptlen);
         char aad[96];
         for (int64_t i = b; i < e; i++) {
@@ -200,11 +221,10 @@ inline int pointstore_encrypt(fspann_pointstore* ps, int64_t h0, int64_t cnt, co
             }
             unsigned char* r = ps->rec(h);
             ps->ver(h)->store(-1, std::memory_order_release);         // being written
-            unsigned char iv[kIvBytes];
-            if (a->RAND_bytes(iv, kIvBytes) != 1) { (*bad)++; continue; }
+            const unsigned char* iv = ivs.data() + static_cast<size_t>(i) * kIvBytes;
             const int al = aad_for(aad, sizeof(aad), h, v, dim);
             std::memcpy(r + 4, iv, kIvBytes);
-            if (!w.seal(key, iv, reinterpret_cast<const unsigned char*>(aad), al, pt.data(), ptlen, r + 4 + kIvBytes)) { (*bad)++; continue; }
+            if (!w.seal(iv, reinterpret_cast<const unsigned char*>(aad), al, pt.data(), ptlen, r + 4 + kIvBytes)) { (*bad)++; continue; }
             ps->ver(h)->store(v, std::memory_order_release);
         }
     });
@@ -219,14 +239,16 @@ inline bool pointstore_open_one(fspann_pointstore* ps, GcmWorker& w, int64_t h, 
         const int v = ps->ver(h)->load(std::memory_order_acquire);
         if (v == 0) return false;                      // never written / deleted: loadPointIfActive() == null
         if (v < 0) { std::this_thread::yield(); continue; }
-        unsigned char key[32];
-        if (!ps->key_for(v, key)) return false;        // retired key: the old ciphertext is unreadable by design
+        if (w.dec_version != v) {     // derivation + the store's key mutex only when the version changes (one batch's worth of life)
+            unsigned char key[32];
+            if (!ps->key_for(v, key) || !w.set_dec_key(v, key)) return false;        // retired key: the old ciphertext is unreadable by design
+        }
         std::memcpy(scratch.data(), ps->rec(h) + 4, kIvBytes + ctlen + kTagBytes);     // snapshot, then re-check the version
         if (ps->ver(h)->load(std::memory_order_acquire) != v) continue;
         char aad[96];
         const int al = aad_for(aad, sizeof(aad), h, v, dim);
         unsigned char* pt = scratch.data() + kIvBytes + ctlen + kTagBytes;
-        if (!w.open(key, scratch.data(), reinterpret_cast<const unsigned char*>(aad), al, scratch.data() + kIvBytes, ctlen, pt)) return false;
+        if (!w.open(scratch.data(), reinterpret_cast<const unsigned char*>(aad), al, scratch.data() + kIvBytes, ctlen, pt)) return false;
         for (int j = 0; j < dim; j++) {                // deserializeVector
             uint64_t bits;
             std::memcpy(&bits, pt + 8 * j, 8);
@@ -247,10 +269,15 @@ inline void pointstore_open_batch(fspann_pointstore* ps, int64_t nq, int64_t B, 
                                   int32_t* out_count, int threads) {
     CryptoApi* a = crypto_api();
     const int dim = ps->dim;
-    parallel_blocks(nq, threads, 1, [&](int, int64_t qb, int64_t qe) {
-        GcmWorker w(a);
-        std::vector<unsigned char> scratch(kIvBytes + 16 * static_cast<size_t>(dim) + kTagBytes + 64);
-        std::vector<double> row(dim);
+    // per-THREAD state (cipher contexts, scratch), created on the thread's first block and kept for the whole call
+    struct PerThread { GcmWorker w; std::vector<unsigned char> scratch; std::vector<double> row;
+                       PerThread(CryptoApi* a, int dim) : w(a), scratch(kIvBytes + 16 * static_cast<size_t>(dim) + kTagBytes + 64), row(dim) {} };
+    std::vector<std::unique_ptr<PerThread>> state(static_cast<size_t>(std::max(1, threads)));
+    parallel_blocks(nq, threads, 2, [&](int wi, int64_t qb, int64_t qe) {
+        if (!state[wi]) state[wi].reset(new PerThread(a, dim));
+        GcmWorker& w = state[wi]->w;
+        std::vector<unsigned char>& scratch = state[wi]->scratch;
+        std::vector<double>& row = state[wi]->row;
         long long okc = 0, badc = 0;
         for (int64_t q = qb; q < qe; q++) {
             const int c = std::max(0, std::min<int>(count[q], static_cast<int>(B)));

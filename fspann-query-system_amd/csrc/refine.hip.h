@@ -450,12 +450,11 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         // QSI.java:137-140: a non-finite query gives an empty result.  Every wave looks at the whole query itself.
         bool qnf = false;
         for (int i = lane; i < d; i += 64) qnf = qnf || !__builtin_isfinite(qrow[i]);
-        const bool qbad = __any(qnf);
-        const int cnt = static_cast<int>(min(static_cast<int64_t>(cnt_raw), B));
-        const int nrows = max(0, min(kRefRows, cnt - r0));
-        const int32_t my_id = (tid < nrows) ? my_id_raw : -1;
+        // The count, this lane's id and the query check are REQUESTED here but first USED after the last tile: the scan
+        // below runs over every row the block holds (tid < rows_here) and the count only decides, in the epilogue, which
+        // rows are scored — so no tile waits for this round trip.
         double s = 0.0;
-        bool ok = GATHER ? (my_id >= 0 && my_id < store_n) : true;
+        bool ok = true;
 
 #define FSP_STREAM_TILE(REG, C0)                                                                                    \
         do {                                                                                                        \
@@ -464,7 +463,7 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
                 *reinterpret_cast<V*>(tile + (slot_row + i * (64 / VPR)) * PITCH + slot_col) = REG[i];               \
             FSP_STREAM_ISSUE(REG);                                                                                  \
             FSP_WAVE_SYNC();                                                                                        \
-            if (tid < nrows) {                                                                                      \
+            if (tid < rows_here) {                                                                                  \
                 const int dc = min(DC, d - (C0));                                                                   \
                 const TC* myrow = tile + tid * PITCH;                                                               \
                 _Pragma("unroll 4") for (int kk = 0; kk < dc; kk += VN) {                                           \
@@ -497,6 +496,11 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
                 for (int i = 0; i < VPR; i++) { const V tmp = regA[i]; regA[i] = regB[i]; regB[i] = tmp; }
             }
         }
+        const bool qbad = __any(qnf);
+        const int cnt = static_cast<int>(min(static_cast<int64_t>(cnt_raw), B));
+        const int nrows = max(0, min(kRefRows, cnt - r0));
+        const int32_t my_id = (tid < nrows) ? my_id_raw : -1;
+        if (GATHER) ok = ok && (my_id >= 0 && my_id < store_n);
         const bool valid = (tid < nrows) && ok && !qbad;
         uint64_t key = kInvalidKey;
         if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371

@@ -74,24 +74,25 @@ __global__ __launch_bounds__(kTickThreads, 4) void tick_kernel(const TickHead h,
         route_lazy_run<kLzThreads>(route, smem, idx, h.n_route, idx);
 #endif
     } else if (role == kTickRefine) {
-        // the scan as a stream (refine_stream_run): this workgroup walks the queries idx, idx + n_refine, ... with the row
-        // loads of the next two tiles always in flight.  First, before any tile is in LDS: queries of its share that the
-        // bounded select handed over one tick ago (count = PENDING) get their Route finished by the full select.
+        // One workgroup per query (refine_scan_block).  Measured alternatives inside this kernel: the streaming scan
+        // (refine_stream_run, a quarter of the workgroups) is 1.4-1.7x slower here than in its own kernel — the shared
+        // kernel is compiled for the register budget of its hungriest role — and made the launch slower overall.
+        const int64_t qi = idx;                                   // nchunks == 1 (host): one workgroup per query
+        int cnt = ref.cand_count[qi];
 #ifndef TICK_NO_FIX
-        if (h.has_fix) {
-            for (int64_t qi = idx; qi < h.nq_refine; qi += h.n_refine) {
-                if (ref.cand_count[qi] != kRoutePending) continue;       // block-uniform
-                // the redo's parameters are read from device memory HERE, in the rare path: as a second RouteParams kernel
-                // argument they would sit in ~80 SGPRs for every role
-                const RouteParams fix = *fix_dev;
-                const int TP = fix.TD * fix.P;
-                route_select_query<false, kTickThreads>(fix, smem, idx, fix.probe_g + qi * TP, fix.nprobe_g + qi * fix.TD, qi);
-            }
+        if (h.has_fix && cnt == kRoutePending) {
+            // the bounded select handed this query over one tick ago: finish its Route with the full select, then scan.
+            // The redo's parameters are read from device memory HERE, in the rare path: as a second RouteParams kernel
+            // argument they would sit in ~80 SGPRs for every role
+            const RouteParams fix = *fix_dev;
+            const int TP = fix.TD * fix.P;
+            route_select_query<false, kTickThreads>(fix, smem, idx, fix.probe_g + qi * TP, fix.nprobe_g + qi * fix.TD, qi);
             __threadfence();
-            __syncthreads();                                      // F_q and the counts are in global memory, LDS is free again
+            __syncthreads();                                      // F_q and its count are in global memory, LDS is free again
+            cnt = __hip_atomic_load(const_cast<int32_t*>(ref.cand_count) + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // not through a stale cache line
         }
 #endif
-        refine_stream_run<float, float, 32, GATHER>(ref, smem, idx, h.n_refine, h.nq_refine, h.has_fix != 0);
+        refine_scan_block<float, float, 32, true, GATHER>(ref, smem, idx, cnt);
     } else {
 #ifndef TICK_NO_ENC
         encode_exact_block<float, kTickEncQB>(enc, idx % h.enc_gx, idx / h.enc_gx, reinterpret_cast<int32_t*>(smem));
