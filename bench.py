@@ -672,27 +672,27 @@ def main():
 
     # ---------------- recall@10 + distance ratio vs exact kNN of the data set (reported, never assumed) ------------------
     recall = ratio = None
+    gt_ms = None
     if rank == 0:
-        with torch.no_grad():
-            Xd = torch.from_numpy(X).to(dev)
-            xx = (Xd * Xd).sum(1)
-            gt = []
-            for s in range(0, Q, 256):
-                qq = q_all[0][s:s + 256]
-                dd = xx[None, :] - 2.0 * (qq @ Xd.T)
-                gt.append(torch.topk(dd, k, dim=1, largest=False).indices)
-            gt = torch.cat(gt).cpu().numpy()
-            del Xd
+        # exact ground truth on the GPU with the reference's own arithmetic and tie rule (fspann_groundtruth_dev =
+        # GroundtruthPrecompute.run), recall@k / distance ratio@k as ForwardSecureANNSystem.computeMetricsAtK defines them
         nv = q_live if args.scaling == "strong" else Q
-        recall = float(np.mean([len(set(gt[i]) & set(got_ids[i])) / k for i in range(nv)]))
-        # distance ratio (ForwardSecureANNSystem.java:798-823): mean over ranks i < k of d(q, ann_i) / d(q, gt_i), queries with k results
-        rsum = []
-        for i in range(nv):
-            if (got_ids[i] >= 0).all():
-                dg = np.sqrt(((Qall[0, i][None, :].astype(np.float64) - X[gt[i]].astype(np.float64)) ** 2).sum(1))
-                if (dg > 0).all():
-                    rsum.append(float(np.mean(got_dist[i] / dg)))
-        ratio = float(np.mean(rsum)) if rsum else None
+        base_ptr = ctx.L.fspann_store_dev_ptr(ctx.handle, None)            # the fp32 rows already resident in HBM
+        gt_d = torch.zeros((Q, k), dtype=torch.int32, device=dev)
+        rec_d = torch.zeros(Q, dtype=torch.float64, device=dev)
+        rat_d = torch.zeros(Q, dtype=torch.float64, device=dev)
+        ann_d = out_ids.contiguous()
+        torch.cuda.synchronize()
+        t_g = time.perf_counter()
+        ctx.groundtruth_dev(n, base_ptr, Q, q_all[0].data_ptr(), d, k, gt_d.data_ptr())
+        ctx.sync()
+        gt_ms = (time.perf_counter() - t_g) * 1e3
+        ctx.eval_metrics_dev(n, base_ptr, Q, q_all[0].data_ptr(), d, k, ann_d.data_ptr(), k, bufs[0]["out_cnt"].data_ptr(), gt_d.data_ptr(), k,
+                             rec_d.data_ptr(), rat_d.data_ptr())
+        ctx.sync()
+        rec_h, rat_h = rec_d.cpu().numpy()[:nv], rat_d.cpu().numpy()[:nv]
+        recall = float(rec_h.mean())
+        ratio = float(np.nanmean(rat_h)) if np.isfinite(rat_h).any() else None
 
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) --------------------------------
     cpu = None
@@ -782,6 +782,8 @@ def main():
                                       "gather": "rows packed into [Q][B][d] by a gather kernel inside the step, then scanned"}[mode]},
             "recall_at_10": recall,
             "distance_ratio_at_10": ratio,
+            "groundtruth": {"kernel": "gt_dist_kernel + gt_select_kernel (exact, GroundtruthPrecompute semantics)", "queries": Q, "base": n,
+                            "ms": round(gt_ms, 1) if gt_ms is not None else None},
             "stages_ms": {"encode": round(float(st_mean[0]), 5), "route_select": round(float(st_mean[1]), 5),
                           "stage_candidates": round(float(st_mean[2]), 5), "refine_topk": round(float(st_mean[3]), 5)},
             "roofline": roofline,

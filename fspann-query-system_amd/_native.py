@@ -143,6 +143,8 @@ _SIGS = {
     "fspann_route_handover_bytes": (_sz, [_vp, _i64, _i]),
     "fspann_tick_dev": (_i, [_vp, C.POINTER(Tick)]),
     "fspann_last_tick_fused": (_i, [_vp]),
+    "fspann_groundtruth_dev": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _vp]),
+    "fspann_eval_metrics_dev": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "fspann_pointstore_create": (_i, [_i64, _i, C.POINTER(_vp)]),
     "fspann_pointstore_destroy": (None, [_vp]),
     "fspann_pointstore_set_master_key": (_i, [_vp, _vp]),

@@ -12,6 +12,7 @@
 
 #include "comm.hip.h"
 #include "encode.hip.h"
+#include "groundtruth.hip.h"
 #include "hostpipe.hip.h"
 #include "refine.hip.h"
 #include "route.hip.h"
@@ -495,7 +496,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits); free_devt(c->d_unmodelled);
     if (c->store_owned) free_dev(c->d_store);
-    free_dev(c->ws_tickfix.p); free_dev(c->d_fixparams);
+    free_dev(c->ws_tickfix.p); free_dev(c->d_fixparams); free_dev(c->ws_gt.p);
     free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
@@ -1914,6 +1915,44 @@ int fspann_pipeline_stats(fspann_pipeline* p, double* route_ms, double* decrypt_
     if (decrypt_ms) *decrypt_ms = p->sum_decrypt_ms / n;
     if (refine_ms) *refine_ms = p->sum_refine_ms / n;
     if (batches) *batches = p->batches;
+    return FSPANN_OK;
+}
+
+// ---- exact ground truth + evaluation metrics (groundtruth.hip.h) -------------------------------------------------------------
+int fspann_groundtruth_dev(fspann_ctx* c, int64_t n, const float* base_dev, int64_t nq, const float* q_dev, int dim, int k, int32_t* out_ids_dev,
+                           double* out_d2_dev) {
+    CHECK_CTX(c);
+    if (!base_dev || !q_dev || !out_ids_dev) return fail(FSPANN_E_NULL, "ground truth buffer is null");
+    if (n <= 0 || n >= (1LL << 31) || nq < 0 || dim <= 0) return fail(FSPANN_E_ARG, "Empty or malformed vector files (zero records).");
+    if (k <= 0 || k > kGtMaxK) return fail(FSPANN_E_ARG, "k must be in [1, %d]", kGtMaxK);
+    if (nq == 0) return FSPANN_OK;
+    // the [chunk x n] fp64 distance matrix lives in scratch: at most ~8 GB at a time
+    const int64_t chunk = std::max<int64_t>(kGtQT, std::min<int64_t>(nq, ((1LL << 33) / (n * 8)) / kGtQT * kGtQT));
+    int rc = ensure(c, c->ws_gt, static_cast<size_t>(chunk) * n * 8);
+    if (rc) return rc;
+    double* dist = static_cast<double*>(c->ws_gt.p);
+    for (int64_t s = 0; s < nq; s += chunk) {
+        const int64_t cq = std::min(chunk, nq - s);
+        dim3 grid(static_cast<unsigned>((n + kGtRows - 1) / kGtRows), static_cast<unsigned>((cq + kGtQT - 1) / kGtQT));
+        hipLaunchKernelGGL(gt_dist_kernel, grid, dim3(kGtRows), 0, c->stream, base_dev, n, q_dev + s * dim, cq, dim, dist);
+        FSP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(gt_select_kernel, dim3(static_cast<unsigned>(cq)), dim3(kGtSelThreads), 0, c->stream, dist, n, k, out_ids_dev + s * k,
+                           out_d2_dev ? out_d2_dev + s * k : nullptr);
+        FSP_HIP(hipGetLastError());
+    }
+    return FSPANN_OK;
+}
+
+int fspann_eval_metrics_dev(fspann_ctx* c, int64_t n, const float* base_dev, int64_t nq, const float* q_dev, int dim, int k, const int32_t* ann_ids_dev,
+                            int64_t ann_stride, const int32_t* ann_count_dev, const int32_t* gt_ids_dev, int64_t gt_stride, double* recall_dev,
+                            double* ratio_dev) {
+    CHECK_CTX(c);
+    if (!base_dev || !q_dev || !ann_ids_dev || !gt_ids_dev || !recall_dev || !ratio_dev) return fail(FSPANN_E_NULL, "metrics buffer is null");
+    if (n <= 0 || nq < 0 || dim <= 0 || k <= 0 || k > 64 || gt_stride < k || ann_stride <= 0) return fail(FSPANN_E_ARG, "k must be in [1, 64] and gt must hold >= k ids per query");
+    if (nq == 0) return FSPANN_OK;
+    hipLaunchKernelGGL(gt_metrics_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), 0, c->stream, base_dev, n, q_dev, dim, k, ann_ids_dev, ann_stride,
+                       ann_count_dev, gt_ids_dev, gt_stride, recall_dev, ratio_dev);
+    FSP_HIP(hipGetLastError());
     return FSPANN_OK;
 }
 

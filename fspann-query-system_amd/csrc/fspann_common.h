@@ -150,6 +150,7 @@ struct fspann_ctx {
     fspann::DevBuf ws_route;   // global hash/sort fallback for the route kernel
     fspann::DevBuf ws_probe;   // probe lists handed from route_probe_kernel to route_select_kernel
     fspann::DevBuf ws_refine;  // per-chunk partial top-k
+    fspann::DevBuf ws_gt;      // [query chunk][n] fp64 distance matrix of fspann_groundtruth_dev
     fspann::DevBuf ws_tickfix; // arenas of the full select run by the refine role of a tick for PENDING queries
     static constexpr int kFixSlots = 8;
     void* d_fixparams = nullptr;         // kFixSlots RouteParams blocks in device memory (parameters of that redo) ...

@@ -296,6 +296,15 @@ class FspannContext:
                                                out_count_ptr, scored_ptr or None, sel_ids_ptr or None, sel_count_ptr or None,
                                                bad_ptr or None))
 
+    def groundtruth_dev(self, n, base_ptr, nq, q_ptr, dim, k, out_ids_ptr, out_d2_ptr=0):
+        """Exact k-NN (GroundtruthPrecompute semantics) of device-resident fp32 base / query rows."""
+        N.check(self.L.fspann_groundtruth_dev(self._h, n, base_ptr, nq, q_ptr, dim, k, out_ids_ptr, out_d2_ptr or None))
+
+    def eval_metrics_dev(self, n, base_ptr, nq, q_ptr, dim, k, ann_ptr, ann_stride, ann_count_ptr, gt_ptr, gt_stride, recall_ptr, ratio_ptr):
+        """recall@k / distance ratio@k per query (ForwardSecureANNSystem.computeMetricsAtK)."""
+        N.check(self.L.fspann_eval_metrics_dev(self._h, n, base_ptr, nq, q_ptr, dim, k, ann_ptr, ann_stride, ann_count_ptr or None, gt_ptr, gt_stride,
+                                               recall_ptr, ratio_ptr))
+
     def route_handover_bytes(self, nq, probe_override=-1) -> int:
         return int(self.L.fspann_route_handover_bytes(self._h, nq, probe_override))
 

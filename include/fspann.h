@@ -277,6 +277,19 @@ int fspann_tick_dev(fspann_ctx* ctx, const fspann_tick* t);
 /* 1 if the last fspann_tick_dev ran as one shared kernel, 0 if it fell back to the stand-alone kernels. */
 int fspann_last_tick_fused(fspann_ctx* ctx);
 
+/* ---- exact ground truth + evaluation metrics --------------------------------------------------------
+ * GroundtruthPrecompute.run (api/.../GroundtruthPrecompute.java:218-272): per query the k base vectors with the smallest
+ * squared L2 distance, ties by LOWER id (:167-171), ascending; the distance arithmetic is the reference's (float
+ * subtraction, fp64 squares summed in dimension order, :142-163), so the ids equal a JVM run's.  base [n][dim], q [nq][dim]
+ * fp32 in device memory (fvecs data); out_ids [nq][k] (-1 beyond n), out_d2 [nq][k] squared distances (may be NULL).
+ * fspann_eval_metrics_dev = ForwardSecureANNSystem.computeMetricsAtK (FSA:770-835): recall@k and distance ratio@k per
+ * query (ratio NaN when the reference yields NaN); ann ids [nq][ann_stride] with ann_count (NULL: all), gt [nq][gt_stride].  */
+int fspann_groundtruth_dev(fspann_ctx* ctx, int64_t n, const float* base_dev, int64_t nq, const float* q_dev, int dim, int k,
+                           int32_t* out_ids_dev, double* out_d2_dev);
+int fspann_eval_metrics_dev(fspann_ctx* ctx, int64_t n, const float* base_dev, int64_t nq, const float* q_dev, int dim, int k,
+                            const int32_t* ann_ids_dev, int64_t ann_stride, const int32_t* ann_count_dev, const int32_t* gt_ids_dev,
+                            int64_t gt_stride, double* recall_dev, double* ratio_dev);
+
 /* ---- host candidate pipeline -------------------------------------------------------------------
  * QSI stage B's host half at batch scale: for every id of F_q the reference does loadPointIfActive (one RocksDB get + one
  * Java-deserialised .point file, PIS:717-724, common/RocksDBMetadataManager.java:530-544) and decryptFromPoint

@@ -977,6 +977,72 @@ void orc_refine(int64_t nq, int d, int64_t B, const double* q, const double* can
     }
 }
 
+// GroundtruthPrecompute (api/.../GroundtruthPrecompute.java:142-189,218-272): squared distance with a FLOAT subtraction per
+// dimension (q[i] and v are floats: Java's binary numeric promotion), fp64 squares summed in order; the k smallest by
+// (distance, id) — HeapK keeps exactly those, idsAscending() orders them by BY_D_THEN_ID.
+void orc_groundtruth(int64_t n, const float* base, int64_t nq, const float* q, int d, int k, int32_t* out_ids, double* out_d2) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t qi = 0; qi < nq; qi++) {
+        std::vector<std::pair<double, int32_t>> all((size_t)n);
+        const float* qr = q + (size_t)qi * d;
+        for (int64_t r = 0; r < n; r++) {
+            const float* v = base + (size_t)r * d;
+            double sum = 0.0;
+            for (int i = 0; i < d; i++) {
+                volatile float df = qr[i] - v[i];      // float arithmetic, rounded to float (no excess precision)
+                double dd = (double)df;
+                sum += dd * dd;
+            }
+            all[(size_t)r] = {sum, (int32_t)r};
+        }
+        const int64_t kk = std::min<int64_t>(k, n);
+        std::partial_sort(all.begin(), all.begin() + kk, all.end());     // pair order = (distance, id): Comparator BY_D_THEN_ID
+        for (int64_t j = 0; j < k; j++) {
+            out_ids[(size_t)qi * k + j] = j < kk ? all[(size_t)j].second : -1;
+            if (out_d2) out_d2[(size_t)qi * k + j] = j < kk ? all[(size_t)j].first : std::numeric_limits<double>::infinity();
+        }
+    }
+}
+
+// ForwardSecureANNSystem.computeMetricsAtK (FSA:770-835) with BaseVectorReader.l2 (FSA:1017-1073).
+void orc_metrics(int64_t n, const float* base, int64_t nq, const float* q, int d, int k, const int32_t* ann, int64_t ann_stride,
+                 const int32_t* ann_count, const int32_t* gt, int64_t gt_stride, double* recall, double* ratio) {
+    auto l2 = [&](const float* qr, int32_t id) {
+        double sum = 0.0;
+        for (int i = 0; i < d; i++) {
+            double dd = (double)qr[i] - (double)base[(size_t)id * d + i];
+            sum += dd * dd;
+        }
+        return std::sqrt(sum);
+    };
+    for (int64_t qi = 0; qi < nq; qi++) {
+        const int na = ann_count ? std::max(0, std::min<int>(ann_count[qi], (int)ann_stride)) : (int)ann_stride;
+        const int32_t* a = ann + (size_t)qi * ann_stride;
+        const int32_t* g = gt + (size_t)qi * gt_stride;
+        int hits = 0;
+        for (int i = 0; i < std::min(k, na); i++) {
+            bool in = false;
+            for (int j = 0; j < k; j++) in = in || g[j] == a[i];
+            hits += in;
+        }
+        recall[qi] = hits / (double)k;
+        double r = std::numeric_limits<double>::quiet_NaN();
+        if (na >= k) {
+            double sum = 0.0;
+            int used = 0;
+            for (int i = 0; i < k; i++) {
+                if (a[i] < 0 || a[i] >= n || g[i] < 0 || g[i] >= n) continue;
+                double dGt = l2(q + (size_t)qi * d, g[i]);
+                if (dGt <= 0) continue;
+                sum += l2(q + (size_t)qi * d, a[i]) / dGt;
+                used++;
+            }
+            if (used == k) r = sum / k;
+        }
+        ratio[qi] = r;
+    }
+}
+
 int orc_num_threads() {
 #if defined(_OPENMP)
     return omp_get_max_threads();

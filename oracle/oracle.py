@@ -335,3 +335,28 @@ def refine(q, cand, cand_ids, cand_count, K):
 
 def num_threads() -> int:
     return lib().orc_num_threads()
+
+
+def groundtruth(base, q, k):
+    """GroundtruthPrecompute.run restated: ids [nq][k] (ties by lower id), squared distances."""
+    base = _c(base, np.float32)
+    q = _c(q, np.float32)
+    n, d = base.shape
+    ids = np.empty((q.shape[0], k), np.int32)
+    d2 = np.empty((q.shape[0], k), np.float64)
+    lib().orc_groundtruth(C.c_int64(n), _p(base), C.c_int64(q.shape[0]), _p(q), C.c_int(d), C.c_int(k), _p(ids), _p(d2))
+    return ids, d2
+
+
+def metrics(base, q, k, ann, ann_count, gt):
+    """ForwardSecureANNSystem.computeMetricsAtK restated: (recall@k, distance ratio@k) per query."""
+    base = _c(base, np.float32)
+    q = _c(q, np.float32)
+    ann = _c(ann, np.int32)
+    gt = _c(gt, np.int32)
+    cnt = None if ann_count is None else _c(ann_count, np.int32)
+    rec = np.empty(q.shape[0], np.float64)
+    rat = np.empty(q.shape[0], np.float64)
+    lib().orc_metrics(C.c_int64(base.shape[0]), _p(base), C.c_int64(q.shape[0]), _p(q), C.c_int(base.shape[1]), C.c_int(k), _p(ann),
+                      C.c_int64(ann.shape[1]), _p(cnt), _p(gt), C.c_int64(gt.shape[1]), _p(rec), _p(rat))
+    return rec, rat
