@@ -11,6 +11,7 @@
 #include <numeric>
 
 #include "comm.hip.h"
+#include "build.hip.h"
 #include "encode.hip.h"
 #include "groundtruth.hip.h"
 #include "hostpipe.hip.h"
@@ -475,6 +476,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
         c->knob_refine_stream = std::min(4, std::max(0, env_int("FSPANN_REFINE_STREAM", 3)));
         c->knob_tick_refine = std::min(4, std::max(1, env_int("FSPANN_TICK_REFINE", 1)));
+        c->knob_gpu_cut = env_int("FSPANN_GPU_CUT", 1) != 0;
         c->knob_tick_fuse = env_int("FSPANN_TICK_FUSE", 1) != 0;
         c->knob_tick_front = std::min(100, std::max(0, env_int("FSPANN_TICK_FRONT", 100)));
     }
@@ -2149,23 +2151,26 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
             for (int64_t i = 0; i < ms - 1; i++) ord[k++] = static_cast<int32_t>(i);
         }
     }
-    // 1) codes for every handle (row h of `vectors`), in chunks
-    std::vector<uint64_t> codes(static_cast<size_t>(n) * TD * W);
+    // 1) codes for every handle (row h of `vectors`), in chunks; they stay in HBM (codes_all[h][td][w]) for the cut
+    const bool gpu_cut = c->knob_gpu_cut != 0;
+    std::vector<uint64_t> codes(gpu_cut ? 0 : static_cast<size_t>(n) * TD * W);
     const int64_t chunk = 1 << 18;
     int rc;
     if ((rc = ensure(c, c->ws_io[0], static_cast<size_t>(std::min(chunk, n)) * d * esz))) return rc;
-    if ((rc = ensure(c, c->ws_io[1], static_cast<size_t>(std::min(chunk, n)) * TD * W * 8))) return rc;
+    if ((rc = ensure(c, c->ws_io[1], gpu_cut ? static_cast<size_t>(n) * TD * W * 8 : static_cast<size_t>(std::min(chunk, n)) * TD * W * 8))) return rc;
     if ((rc = ensure(c, c->ws_io[2], static_cast<size_t>(std::min(chunk, n)) * 4))) return rc;
+    uint64_t* codes_all = static_cast<uint64_t*>(c->ws_io[1].p);
     std::vector<int32_t> bad(static_cast<size_t>(std::min(chunk, n)));
     for (int64_t s = 0; s < n; s += chunk) {
         const int64_t cn = std::min(chunk, n - s);
         FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, static_cast<const char*>(vectors) + static_cast<size_t>(s) * d * esz,
                                static_cast<size_t>(cn) * d * esz, hipMemcpyHostToDevice, c->stream));
-        rc = fspann_encode_dev(c, cn, c->ws_io[0].p, dtype, static_cast<uint64_t*>(c->ws_io[1].p), nullptr,
-                               static_cast<int32_t*>(c->ws_io[2].p));
+        uint64_t* cdst = gpu_cut ? codes_all + static_cast<size_t>(s) * TD * W : codes_all;
+        rc = fspann_encode_dev(c, cn, c->ws_io[0].p, dtype, cdst, nullptr, static_cast<int32_t*>(c->ws_io[2].p));
         if (rc) return rc;
-        FSP_HIP(hipMemcpyAsync(codes.data() + static_cast<size_t>(s) * TD * W, c->ws_io[1].p, static_cast<size_t>(cn) * TD * W * 8,
-                               hipMemcpyDeviceToHost, c->stream));
+        if (!gpu_cut)
+            FSP_HIP(hipMemcpyAsync(codes.data() + static_cast<size_t>(s) * TD * W, cdst, static_cast<size_t>(cn) * TD * W * 8,
+                                   hipMemcpyDeviceToHost, c->stream));
         FSP_HIP(hipMemcpyAsync(bad.data(), c->ws_io[2].p, static_cast<size_t>(cn) * 4, hipMemcpyDeviceToHost, c->stream));
         FSP_HIP(hipStreamSynchronize(c->stream));
         for (int64_t i = 0; i < cn; i++)
@@ -2210,8 +2215,73 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
             }
         }
     }
+    if (gpu_cut) {
+        // ---- the cut on the GPU (build.hip.h): (bin, position) order once, then per table a stable radix sort by key + cut ----
+        const int nblocks = static_cast<int>((n + kRsTile - 1) / kRsTile);
+        const int64_t np = (n + S - 1) / S;
+        const size_t kb = static_cast<size_t>(n) * 8, pb = static_cast<size_t>(n) * 4;
+        auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+        // scratch: ord, bucket, perm0, 2 x keys, 2 x payload, hist, per-table outputs
+        const size_t need = al(pb) * 3 + al(kb) * 2 + al(pb) * 2 + al(static_cast<size_t>(256) * nblocks * 4) + al(np * 8) * 2 + al(np * W * 8) + al((np + 1) * 8) + al(pb);
+        if ((rc = ensure(c, c->ws_io[3], need))) return rc;
+        char* w = static_cast<char*>(c->ws_io[3].p);
+        auto take = [&](size_t bytes) { char* q = w; w += al(bytes); return q; };
+        int32_t* d_ord = reinterpret_cast<int32_t*>(take(pb));
+        uint32_t* d_bucket = reinterpret_cast<uint32_t*>(take(pb));
+        uint32_t* d_perm0 = reinterpret_cast<uint32_t*>(take(pb));
+        uint64_t* d_key[2] = {reinterpret_cast<uint64_t*>(take(kb)), reinterpret_cast<uint64_t*>(take(kb))};
+        uint32_t* d_pay[2] = {reinterpret_cast<uint32_t*>(take(pb)), reinterpret_cast<uint32_t*>(take(pb))};
+        uint32_t* d_hist = reinterpret_cast<uint32_t*>(take(static_cast<size_t>(256) * nblocks * 4));
+        int64_t* d_min = reinterpret_cast<int64_t*>(take(np * 8));
+        int64_t* d_max = reinterpret_cast<int64_t*>(take(np * 8));
+        uint64_t* d_repo = reinterpret_cast<uint64_t*>(take(np * W * 8));
+        int64_t* d_offo = reinterpret_cast<int64_t*>(take((np + 1) * 8));
+        int32_t* d_idso = reinterpret_cast<int32_t*>(take(pb));
+        FSP_HIP(hipMemcpyAsync(d_ord, ord.data(), pb, hipMemcpyHostToDevice, c->stream));
+        FSP_HIP(hipMemcpyAsync(d_bucket, bucket.data(), pb, hipMemcpyHostToDevice, c->stream));
+        const unsigned eg = static_cast<unsigned>((n + 255) / 256);
+        // stable LSD radix sort of (key, payload) on the byte digits [p_lo, p_hi]; returns the buffer index holding the result
+        auto radix = [&](int cur, int p_lo, int p_hi) -> int {
+            for (int p = p_lo; p <= p_hi; p++) {
+                hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(kRsThreads), 0, c->stream, d_key[cur], n, 8 * p, d_hist, nblocks);
+                hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(256), 0, c->stream, d_hist, nblocks);
+                hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(kRsThreads), 0, c->stream, d_key[cur], d_pay[cur], n, 8 * p, d_hist, nblocks,
+                                   d_key[cur ^ 1], d_pay[cur ^ 1]);
+                cur ^= 1;
+            }
+            return cur;
+        };
+        // (a) staged positions ordered by (bin at the map's final table length, position)
+        hipLaunchKernelGGL(build_bin_keys_kernel, dim3(eg), dim3(256), 0, c->stream, d_bucket, n, d_key[0], d_pay[0]);
+        int capbits = 0;
+        while ((1 << capbits) < capf) capbits++;
+        int cur = radix(0, 0, std::max(0, (capbits + 7) / 8 - 1));
+        FSP_HIP(hipMemcpyAsync(d_perm0, d_pay[cur], pb, hipMemcpyDeviceToDevice, c->stream));
+        FSP_HIP(hipGetLastError());
+        // (b) per table: keys of that sequence, stable sort by key over the bytes that can differ, cut
+        const int sig = std::min(63, c->bits);                  // key bits [63 - sig, 62] carry code bits
+        const int p_lo = (63 - sig) / 8, p_hi = 7;
+        for (int td = 0; td < TD; td++) {
+            hipLaunchKernelGGL(build_table_keys_kernel, dim3(eg), dim3(256), 0, c->stream, codes_all, TD, W, td, d_ord, d_perm0, n, d_key[0], d_pay[0]);
+            cur = radix(0, p_lo, p_hi);
+            hipLaunchKernelGGL(build_cut_kernel, dim3(eg), dim3(256), 0, c->stream, d_key[cur], d_pay[cur], d_ord, codes_all, TD, W, td, n, S, d_min, d_max,
+                               d_repo, d_offo, d_idso);
+            FSP_HIP(hipGetLastError());
+            auto& mn = c->h_min[td]; auto& mx = c->h_max[td]; auto& rp = c->h_rep[td]; auto& of = c->h_off[td]; auto& ii = c->h_ids[td];
+            mn.resize(np); mx.resize(np); rp.resize(static_cast<size_t>(np) * W); of.resize(np + 1); ii.resize(n);
+            FSP_HIP(hipMemcpyAsync(mn.data(), d_min, np * 8, hipMemcpyDeviceToHost, c->stream));
+            FSP_HIP(hipMemcpyAsync(mx.data(), d_max, np * 8, hipMemcpyDeviceToHost, c->stream));
+            FSP_HIP(hipMemcpyAsync(rp.data(), d_repo, static_cast<size_t>(np) * W * 8, hipMemcpyDeviceToHost, c->stream));
+            FSP_HIP(hipMemcpyAsync(of.data(), d_offo, (np + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+            FSP_HIP(hipMemcpyAsync(ii.data(), d_idso, pb, hipMemcpyDeviceToHost, c->stream));
+            FSP_HIP(hipStreamSynchronize(c->stream));       // the outputs of this table are on the host before the scratch is reused
+            c->h_table_set[td] = 1;
+        }
+        c->dev_index_dirty = true;
+        return fspann_finalize(c);
+    }
     struct Ent { int64_t key; uint32_t bucket; int32_t pos; };
-    // one host thread per table (the cut is independent per (t,d)); the GPU radix-sort version is a "next" item
+    // host cut (FSPANN_GPU_CUT=0): one host thread per table
     const unsigned hw = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16u));
     std::atomic<int> next_td{0};
     std::atomic<bool> worker_oom{false};
