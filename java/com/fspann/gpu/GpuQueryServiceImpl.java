@@ -1,0 +1,163 @@
+package com.fspann.gpu;
+
+import com.fspann.common.EncryptedPoint;
+import com.fspann.common.KeyLifeCycleService;
+import com.fspann.common.KeyVersion;
+import com.fspann.common.QueryResult;
+import com.fspann.common.QueryToken;
+import com.fspann.config.SystemConfig;
+import com.fspann.crypto.CryptoService;
+import com.fspann.crypto.ReencryptionTracker;
+import com.fspann.query.core.QueryTokenFactory;
+import com.fspann.query.service.QueryService;
+
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.util.ArrayList;
+import java.util.Collections;
+import java.util.HashSet;
+import java.util.List;
+import java.util.Set;
+
+/**
+ * Drop-in for QueryServiceImpl (query/src/main/java/com/fspann/query/service/QueryServiceImpl.java:101-352): the same
+ * control flow — decrypt the query, Route, keep the first B (stage A.5), load + decrypt each candidate ON THE HOST
+ * (QSI:238-271, unchanged: loadPointIfActive + CryptoService.decryptFromPoint with the point's own key version), score,
+ * stable top-K, one adaptive retry with 10 probes — with Route and the distance / top-K part of Refine on the GPU.
+ * The decrypted rows are packed into one direct buffer and handed to fspann_refine; nothing encrypted or keyed ever
+ * reaches the device.  Metric getters mirror QSI:417-474.  Not re-entrant per instance, like the reference (QSI:45-64).
+ *
+ * Not compiled in the build container (no JDK); Python twin: operators.py (class QueryServiceImpl), tested.
+ */
+public final class GpuQueryServiceImpl implements QueryService {
+    private final GpuPartitionedIndexService index;
+    private final CryptoService cryptoService;
+    private final KeyLifeCycleService keyService;
+    private final QueryTokenFactory tokenFactory;
+    private final SystemConfig cfg;
+    private ReencryptionTracker reencTracker;
+    private final ThreadLocal<Integer> refinementLimitOverride = ThreadLocal.withInitial(() -> -1);   // QSI:454-466
+    private final Set<String> touchedThisSession = new HashSet<>();
+    private volatile long lastServerNs, lastClientNs, lastDecryptNs;
+    private volatile int lastCandTotal, lastCandKept, lastCandDecrypted, lastReturned, lastUniqueCandidates, lastEffectiveLimit;
+    private volatile List<String> lastFinalIds = Collections.emptyList();
+
+    public GpuQueryServiceImpl(GpuPartitionedIndexService index, CryptoService cryptoService, KeyLifeCycleService keyService,
+                               QueryTokenFactory tf, SystemConfig cfg) {
+        this.index = java.util.Objects.requireNonNull(index, "index");
+        this.cryptoService = java.util.Objects.requireNonNull(cryptoService, "cryptoService");
+        this.keyService = java.util.Objects.requireNonNull(keyService, "keyService");
+        this.tokenFactory = tf;
+        this.cfg = java.util.Objects.requireNonNull(cfg, "cfg");
+    }
+
+    private static ByteBuffer buf(long bytes) { return ByteBuffer.allocateDirect((int) bytes).order(ByteOrder.nativeOrder()); }
+
+    private static boolean isValid(double[] v) {                                // QSI:407-413
+        if (v == null) return false;
+        for (double x : v) if (Double.isNaN(x) || Double.isInfinite(x)) return false;
+        return true;
+    }
+
+    @Override public List<QueryResult> search(QueryToken token) {
+        if (token == null) return Collections.emptyList();                      // QSI:102-104
+        touchedThisSession.clear();                                             // QSI:120
+        final long t0 = System.nanoTime();
+        long decryptNs = 0;
+        final double[] q;
+        try {                                                                    // QSI:124-135
+            KeyVersion kv;
+            try { kv = keyService.getVersion(token.getVersion()); } catch (RuntimeException e) { kv = keyService.getCurrentVersion(); }
+            q = cryptoService.decryptQuery(token.getEncryptedQuery(), token.getIv(), kv.getKey());
+        } catch (RuntimeException e) {
+            return Collections.emptyList();
+        }
+        if (!isValid(q)) return Collections.emptyList();                         // QSI:137-140
+        final int K = token.getTopK(), dim = q.length;
+        boolean retried = false;
+        try {
+            while (true) {
+                int limit = getEffectiveRefinementLimit(cfg.getRuntime().getRefinementLimit());
+                lastEffectiveLimit = limit;
+                int[] kept = new int[1];
+                // stage A + A.5 on the GPU: the first `limit` entries of the reference's list (HashMap order, stable by score)
+                List<GpuPartitionedIndexService.CandidateWithScore> fq = index.route(token, limit, true, kept);
+                lastCandTotal = index.getLastRawCandidateCount();
+                lastCandKept = kept[0];
+                lastUniqueCandidates = fq.size();
+                if (fq.isEmpty()) { lastReturned = 0; return Collections.emptyList(); }
+                // stage B, host part — exactly the reference's loop (QSI:238-271): load, decrypt with the point's own version, validate
+                final long td0 = System.nanoTime();
+                ByteBuffer rows = buf(8L * fq.size() * dim), ids = buf(4L * fq.size());
+                List<String> rowId = new ArrayList<>(fq.size());
+                for (GpuPartitionedIndexService.CandidateWithScore c : fq) {
+                    try {
+                        EncryptedPoint ep = index.loadPointIfActive(c.id());
+                        if (ep == null) continue;
+                        double[] v = cryptoService.decryptFromPoint(ep, keyService.getVersion(ep.getKeyVersion()).getKey());
+                        if (!isValid(v) || v.length != dim) continue;
+                        for (double x : v) rows.putDouble(x);
+                        ids.putInt(rowId.size());
+                        rowId.add(c.id());
+                        touchedThisSession.add(c.id());
+                    } catch (Exception e) {
+                        // per-candidate failures are swallowed (QSI:264-269)
+                    }
+                }
+                decryptNs += System.nanoTime() - td0;
+                lastCandDecrypted = rowId.size();
+                if (rowId.isEmpty()) { lastReturned = 0; return Collections.emptyList(); }
+                // stage B distances + stage C on the GPU: sequential fp64 L2 (QSI:364-372), stable sort, first K (QSI:298-316)
+                int B = rowId.size();
+                ByteBuffer qb = buf(8L * dim), nb = buf(4), oi = buf(4L * K), od = buf(8L * K), oc = buf(4), sc = buf(4);
+                for (double x : q) qb.putDouble(x);
+                nb.putInt(B);
+                FspannNative.check(FspannNative.refine(index.nativeContext(), 1, qb, rows, FspannNative.F64, B, ids, nb, K, oi, od, oc, sc));
+                int eff = oc.getInt(0);
+                List<QueryResult> out = new ArrayList<>(eff);
+                List<String> fin = new ArrayList<>(eff);
+                for (int i = 0; i < eff; i++) {
+                    String id = rowId.get(oi.getInt(4 * i));
+                    out.add(new QueryResult(id, od.getDouble(8 * i)));
+                    fin.add(id);
+                }
+                lastReturned = eff;
+                lastFinalIds = fin;
+                if (!retried && (lastReturned < K || lastCandDecrypted < 10 * K)) {   // QSI:327-337,444-447
+                    retried = true;
+                    index.setProbeOverride(10);
+                    continue;                                                        // touchedThisSession keeps both passes (QSI:120)
+                }
+                return out;
+            }
+        } finally {                                                              // QSI:342-351
+            index.clearProbeOverride();
+            lastServerNs = System.nanoTime() - t0;
+            lastDecryptNs = decryptNs;
+            lastClientNs = 0;
+            if (reencTracker != null && !touchedThisSession.isEmpty()) reencTracker.record(new HashSet<>(touchedThisSession));
+        }
+    }
+
+    // ---- accessors of QueryServiceImpl (QSI:83-87,417-474) ----------------------------------------------------------------
+    public void setReencryptionTracker(ReencryptionTracker tr) { this.reencTracker = tr; }
+    public List<String> getLastFinalResultIds() { return lastFinalIds; }
+    public long getLastQueryDurationNs() { return lastServerNs; }
+    public long getLastClientDurationNs() { return lastClientNs; }
+    public long getLastDecryptNs() { return lastDecryptNs; }
+    public int getLastCandTotal() { return lastCandTotal; }
+    public int getLastCandKept() { return lastCandKept; }
+    public Set<String> getLastCandidateIds() { return index.getLastTouchedIds(); }
+    public int getLastCandDecrypted() { return lastCandDecrypted; }
+    public int getLastReturned() { return lastReturned; }
+    public QueryToken deriveToken(QueryToken base, int k) {
+        if (tokenFactory == null) throw new IllegalStateException("QueryTokenFactory not available");
+        return tokenFactory.derive(base, k);
+    }
+    public void setRefinementLimit(int limit) { refinementLimitOverride.set(limit); }
+    public void clearRefinementLimit() { refinementLimitOverride.set(-1); }
+    public int getEffectiveRefinementLimit(int defaultLimit) { int o = refinementLimitOverride.get(); return o > 0 ? o : defaultLimit; }
+    public int getLastEffectiveRefinementLimit() { return lastEffectiveLimit; }
+    public int getLastUniqueCandidates() { return lastUniqueCandidates; }
+    public double getLastRefinementUtilization() { return lastEffectiveLimit > 0 ? (double) lastCandDecrypted / lastEffectiveLimit : 0.0; }
+}

@@ -13,8 +13,9 @@ import java.util.List;
 import java.util.Map;
 
 /**
- * Adapter the patched PartitionedIndexService / QueryTokenFactory / QueryServiceImpl delegate to
- * (INTEGRATION.md §3 shows the three call sites).  It owns the String id <-> int handle map and the
+ * Low-level adapter for callers that IMPORT the JVM's own frozen partitions (exportTable) instead of letting the library
+ * cut them (GpuPartitionedIndexService does the latter and is the drop-in class; this one is what a patched
+ * PartitionedIndexService would delegate to, INTEGRATION.md).  It owns the String id <-> int handle map and the
  * native context; AES-GCM, key versions and RocksDB stay exactly where they are in the reference.
  *
  * Not compiled in the build container (no JDK); it is the JVM twin of fspann-query-system_amd/operators.py,
@@ -30,8 +31,10 @@ public final class GpuRouteRefine implements AutoCloseable {
                           int probeOverride, int maxGlobalCandidates, int refinementLimit, int hammingThreshold) {
         this.tables = tables; this.divisions = divisions; this.m = m; this.lambda = lambda; this.dim = dim;
         this.words = (m * lambda + 63) / 64;
-        this.ctx = FspannNative.ctxCreate(device, new int[]{tables, divisions, m, lambda, dim, 64, 5, probeOverride,
-                maxGlobalCandidates, refinementLimit, hammingThreshold});
+        long[] h = new long[1];
+        FspannNative.check(FspannNative.ctxCreate(device, new int[]{tables, divisions, m, lambda, dim, 64, 5, probeOverride,
+                maxGlobalCandidates, refinementLimit, hammingThreshold, 0}, h));
+        this.ctx = h[0];
     }
 
     private static ByteBuffer buf(long bytes) {
@@ -51,7 +54,7 @@ public final class GpuRouteRefine implements AutoCloseable {
                     w.putDouble(g.omega[j]);
                 }
             }
-        FspannNative.check(FspannNative.setGFunctions(ctx, a, r, w));
+        FspannNative.check(FspannNative.setGfunctions(ctx, a, r, w));
     }
 
     /** Export the frozen partitions of one (t,d) (DivisionState.partitions, PIS:111-113) after PIS.build. */

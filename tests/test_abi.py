@@ -100,3 +100,21 @@ def test_operator_surface_host_checks(pkg):
     t2 = tf.derive(tok, 7)
     assert t2.getTopK() == 7 and np.array_equal(t2.getBitCodes(), tok.getBitCodes())
     assert ops._java_string_hash("hello") == 99162322 and ops._java_string_hash("1000000") == 1958013297
+
+
+def test_jni_shim_binds_every_header_symbol_and_type_checks():
+    """jni/fspann_jni.cpp + FspannNative.java are generated from the header (tools/gen_jni.py): one native method per entry
+    point.  No JDK exists here, so the shim is type-checked against tests/jni_stub/jni.h (syntax check only, never linked)."""
+    import subprocess
+    bound = open(os.path.join(ROOT, "jni", "bound_symbols.txt")).read().split()
+    assert sorted(bound) == header_symbols()
+    java = open(os.path.join(ROOT, "java", "com", "fspann", "gpu", "FspannNative.java")).read()
+    assert java.count("public static native") == len(bound)
+    # regenerating gives the committed files (the header and the shim cannot drift apart)
+    before = {f: open(os.path.join(ROOT, f)).read() for f in ("jni/fspann_jni.cpp", "java/com/fspann/gpu/FspannNative.java")}
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_jni.py")], stdout=subprocess.DEVNULL)
+    for f, txt in before.items():
+        assert open(os.path.join(ROOT, f)).read() == txt, f + " is stale: run tools/gen_jni.py"
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "fspann_jni.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:2000]
