@@ -188,7 +188,10 @@ def main():
     ctx = pkg.FspannContext(cfg, local_rank)
     ctx.registry_initialize(X[:1000].astype(np.float64))   # GFunctionRegistry.initialize from the first 1000 vectors
     ctx.set_id_meta(n)
+    t_b = time.time()
     ctx.build_index(X)                                      # GPU coding (MFMA pre-filter + exact re-check) + partition cut
+    ctx.sync()
+    setup_build_s = time.time() - t_b
     ctx.store_set(X)                                        # plaintext rows: source of the dense blocks / the store variant
     ctxs = [ctx]
     nctx = max(1, args.contexts) if args.pipeline == "concurrent" else 1
@@ -777,11 +780,14 @@ def main():
                              "kernels on its own HIP stream (hardware queues overlap Route of one batch with Refine of another)" % nctx) if nctx > 1
                        else "serial: encode, Route, Refine of one batch as three kernels on one stream",
                        "candidates": {"dense": "kernel path (SURVEY 8d): [Q][B][d] blocks of decrypted candidate rows resident in HBM before the timed "
-                                               "region (packed once per distinct batch), scanned by refine_scan_kernel",
+                                               "region (packed once per distinct batch), scanned by refine_stream_kernel",
                                       "store": "trusted-HBM variant: rows read from an HBM-resident plaintext store by id inside the refine scan",
                                       "gather": "rows packed into [Q][B][d] by a gather kernel inside the step, then scanned"}[mode]},
             "recall_at_10": recall,
             "distance_ratio_at_10": ratio,
+            "setup": {"build_index_s": round(setup_build_s, 3),
+                      "note": "fspann_build_index of the whole base set: H2D of the vectors, coding (MFMA pre-filter + exact re-check), "
+                              "radix sorts + partition cut of every table on the GPU, treeify replay of the staging map on the host"},
             "groundtruth": {"kernel": "gt_dist_kernel + gt_select_kernel (exact, GroundtruthPrecompute semantics)", "queries": Q, "base": n,
                             "ms": round(gt_ms, 1) if gt_ms is not None else None},
             "stages_ms": {"encode": round(float(st_mean[0]), 5), "route_select": round(float(st_mean[1]), 5),

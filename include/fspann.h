@@ -106,8 +106,9 @@ int fspann_set_id_meta(fspann_ctx* ctx, int64_t n_ids, const int32_t* java_hash,
 int fspann_finalize(fspann_ctx* ctx);
 
 /* Native Setup (replaces PIS.insert's coding loop PIS:331-346 + PIS.build
- * PIS:372-434 + GreedyPartitioner.build): codes all n vectors on the GPU with the exact
- * fp64 kernel and cuts partitions.  `order[n]` = handles in the order they reach `staged`
+ * PIS:372-434 + GreedyPartitioner.build): codes all n vectors on the GPU (MFMA fp32 pre-filter + exact fp64
+ * re-check for n >= 4096, the exact fp64 kernel otherwise: bit-identical codes either way) and cuts the partitions on
+ * the GPU too (stable radix sort by key of the HashMap iteration order, csrc/build.hip.h).  `order[n]` = handles in the order they reach `staged`
  * (NULL: the stock pipeline's 999,1000,..,n-1,0,..,998).  vectors = [n][dim]
  * host, row h = handle h.  Requires set_gfunctions + set_id_meta first.  Freezes ctx.     */
 int fspann_build_index(fspann_ctx* ctx, int64_t n, const void* vectors, int dtype, const int32_t* order);

@@ -268,3 +268,25 @@ def test_zz_bounded_select_was_exercised():
     """The scenes above must have driven the bounded select itself, and its hand-back to the full select."""
     assert sum(1 for r in LAZY_RUNS if r["lazy"]) >= 10
     assert any(r["lazy"] and r["overflowed"] == 0 for r in LAZY_RUNS)
+
+
+def test_hamming_prefilter_threshold_is_order_equivalent(pkg, oracle):
+    """runtime.hammingPrefilterThreshold tau > 0 (QSI:169-206): every candidate with score <= tau first, then the rest until B.
+    The list is already stable-sorted by score, so stage A.5 keeps the same first B whatever tau is — asserted against the
+    oracle's literal two-pass selection for tau in {4, 7} (the values of the reference's *_sub1.json profiles)."""
+    for tau in (4, 7):
+        sc = make_scene(oracle, n=20000, d=16, T=6, D=2, m=12, lam=2, B=150, tau=tau, seed=90 + tau)
+        o = sc["oracle"]
+        Q = sc["rng"].standard_normal((32, 16)).astype(np.float32)
+        ref = o.search(Q.astype(np.float64), 10)
+        codes = o.encode(Q.astype(np.float64))
+        with ctx_for(pkg, sc) as ctx:
+            ctx.build_index(sc["X"])
+            rt = ctx.route(codes, limit=150)
+            ctx.set_route_mode(2)
+            rt2 = ctx.route(codes, limit=150, counters=False)
+        assert np.array_equal(rt["count"], ref["sel_count"]) and np.array_equal(rt2["count"], ref["sel_count"])
+        sel = np.where(np.arange(150)[None] < rt["count"][:, None], rt["ids"][:, :150], -1)
+        assert np.array_equal(sel, ref["sel"][:, :150])
+        assert np.array_equal(rt2["ids"], rt["ids"])
+        assert (rt["score"][np.arange(32), 0] <= tau).any()        # the threshold actually splits some lists
