@@ -473,7 +473,7 @@ def main():
     st_mean = stage_ms.mean(axis=0)
 
     # ---------------- extra passes (N = 1; reported beside `value`, never as it) -------------------------------------------
-    variants, hbm_proof, cfg4_shape, peak_measured = {}, None, None, None
+    variants, hbm_proof, cfg4_shape, peak_measured, peak_launch_sized = {}, None, None, None, None
     if extras:
         if use_tick or nctx > 1:
             el_s, _, _ = timed(mode, args.steps, max(2, args.warmup))
@@ -577,6 +577,8 @@ def main():
             traffic = None
     if extras:
         peak_measured = round(ctx.hbm_read_peak(1 << 32, 5), 1)      # pure 16-byte-load kernel over 4 GiB, best of 5
+        # the same pure-load kernel when one launch reads only as many bytes as one refinement scan does (cold windows of 4 GiB)
+        peak_launch_sized = round(ctx.hbm_read_window(1 << 32, (Q * (B * d * 4 + d * 4 + k * 8) + 15) // 16 * 16, 24), 1)
         # (a) the same scan reading 1024 x 256 random rows of an 8 M x 128 (4.1 GB) store: 134 MB per launch out of 4.1 GB
         NS = 8_000_000
         big = torch.randn((NS, d), dtype=torch.float32, device=dev)
@@ -642,6 +644,8 @@ def main():
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, peak_spec=HBM_PEAK_GBS,
                     peak_measured=peak_measured, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     frac_of_measured=round(achieved / peak_measured, 4) if peak_measured else None,
+                    peak_launch_sized=peak_launch_sized,
+                    frac_of_launch_sized=round(achieved / peak_launch_sized, 4) if peak_launch_sized else None,
                     traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5), launches=ref_launches,
                     working_set_bytes=(NB * Q * B * d * 4) if mode == "dense" else n * d * 4,

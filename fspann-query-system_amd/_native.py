@@ -172,6 +172,7 @@ _SIGS = {
     "fspann_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_char_p)]),
     "fspann_allgather_topk_dev": (_i, [_vp, _i64, _i, _vp, _vp]),
     "fspann_hbm_read_peak": (_i, [_vp, _sz, _i, C.POINTER(C.c_double)]),
+    "fspann_hbm_read_window": (_i, [_vp, _sz, _sz, _i, C.POINTER(C.c_double)]),
     "fspann_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "fspann_dev_free": (_i, [_vp, _vp]),
     "fspann_h2d": (_i, [_vp, _vp, _vp, _sz]),

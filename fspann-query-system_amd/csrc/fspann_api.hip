@@ -339,7 +339,7 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     const bool vec = (d % VN == 0) && ((reinterpret_cast<uintptr_t>(cand) & 15) == 0);
     const size_t lds = std::max<size_t>(static_cast<size_t>(kRefRows) * (vec ? DC + VN : DC + 1) * sizeof(TC), static_cast<size_t>(kRefRows) * 16);
     const unsigned grid = static_cast<unsigned>(nq * nchunks);
-    const RefineArgs<TC, TQ> ra{q, cand, GATHER ? c->store_n : 0, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt};
+    const RefineArgs<TC, TQ> ra{q, cand, GATHER ? c->store_n : 0, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt, c->dbg_route};
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {   // start/stop events attached to this very dispatch
@@ -352,11 +352,14 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     };
     int lrc = FSPANN_OK;
     bool streamed = false;
-    if constexpr (DC * sizeof(TC) == 128) if (vec && c->knob_refine_stream > 0) {
+    // workgroups per CU of the streaming scan: dense blocks run at 128 registers (4 per CU: a 1024-query batch is exactly one
+    // unit per workgroup on 256 CUs), the store gather at 3 per CU; FSPANN_REFINE_STREAM overrides, 0 = per-query scan
+    const int stream_wgs = (c->knob_refine_stream >= 0) ? std::min(c->knob_refine_stream, GATHER ? 3 : 4) : (GATHER ? 3 : 4);
+    if constexpr (DC * sizeof(TC) == 128) if (vec && stream_wgs > 0) {
         // the scan as a stream: knob_refine_stream workgroups per CU, each walking several (query, chunk) units with the loads
         // of the next two tiles in flight across unit boundaries (refine_stream_run)
         const int64_t units = nq * nchunks;
-        const unsigned sgrid = static_cast<unsigned>(std::min<int64_t>(units, static_cast<int64_t>(c->num_cus) * c->knob_refine_stream));
+        const unsigned sgrid = static_cast<unsigned>(std::min<int64_t>(units, static_cast<int64_t>(c->num_cus) * stream_wgs));
         auto kern = refine_stream_kernel<TC, TQ, DC, GATHER>;
         if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {
             hipExtLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, c->rt_events[c->rt_used], c->rt_events[c->rt_used + 1], 0, ra, nq);
@@ -474,7 +477,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_lazy_cap = std::max(0, env_int("FSPANN_ROUTE_LAZY_CAP", 0));
         c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
-        c->knob_refine_stream = std::min(4, std::max(0, env_int("FSPANN_REFINE_STREAM", 3)));
+        c->knob_refine_stream = std::min(4, std::max(-1, env_int("FSPANN_REFINE_STREAM", -1)));   // -1: 4 per CU dense, 3 per CU gather
         c->knob_tick_refine = std::min(4, std::max(1, env_int("FSPANN_TICK_REFINE", 1)));
         c->knob_gpu_cut = env_int("FSPANN_GPU_CUT", 1) != 0;
         c->knob_tick_fuse = env_int("FSPANN_TICK_FUSE", 1) != 0;
@@ -2077,6 +2080,43 @@ int fspann_hbm_read_peak(fspann_ctx* c, size_t bytes, int reps, double* gb_per_s
             if (ms > 0.f) best = std::max(best, static_cast<double>(bytes) / (ms * 1e-3) / 1e9);
         }
         *gb_per_s = best;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    (void)hipFree(sink);
+    return rc;
+}
+
+int fspann_hbm_read_window(fspann_ctx* c, size_t bytes, size_t window, int reps, double* gb_per_s) {
+    CHECK_CTX(c);
+    if (!gb_per_s || reps <= 0 || window < (1u << 20) || bytes < 2 * window || (window & 15))
+        return fail(FSPANN_E_ARG, "window < 1 MiB or not a multiple of 16, bytes < 2 windows, reps <= 0 or null output");
+    void* buf = nullptr;
+    unsigned long long* sink = nullptr;
+    FSP_HIP(hipMalloc(&buf, bytes));
+    if (hipMalloc(&sink, 8) != hipSuccess) { (void)hipFree(buf); return fail(FSPANN_E_NOMEM, "hipMalloc failed"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = FSPANN_OK;
+    do {
+        if (hipMemsetAsync(buf, 0x5A, bytes, c->stream) != hipSuccess || hipMemsetAsync(sink, 0, 8, c->stream) != hipSuccess ||
+            hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = fail(FSPANN_E_DEVICE, "setup failed"); break; }
+        const unsigned grid = static_cast<unsigned>(c->num_cus) * 8;
+        const size_t nwin = bytes / window;
+        hipLaunchKernelGGL(hbm_read_kernel, dim3(grid), dim3(256), 0, c->stream, static_cast<const uint4*>(buf), window / 16, sink);   // warm-up
+        double total_ms = 0.0;
+        int done = 0;
+        for (int r = 0; r < reps; r++) {
+            const char* w = static_cast<const char*>(buf) + (static_cast<size_t>(r + 1) % nwin) * window;
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(FSPANN_E_DEVICE, "hbm_read_kernel failed"); break; }
+            hipExtLaunchKernelGGL(hbm_read_kernel, dim3(grid), dim3(256), 0, c->stream, e0, e1, 0, reinterpret_cast<const uint4*>(w), window / 16, sink);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(FSPANN_E_DEVICE, "hbm_read_kernel failed"); break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            total_ms += ms;
+            done++;
+        }
+        if (rc == FSPANN_OK) *gb_per_s = (total_ms > 0.0) ? static_cast<double>(window) * done / (total_ms * 1e-3) / 1e9 : 0.0;
     } while (0);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

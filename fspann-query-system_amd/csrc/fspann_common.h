@@ -85,7 +85,7 @@ struct fspann_ctx {
     int knob_lazy_cap = 0;           // FSPANN_ROUTE_LAZY_CAP: entries one query may hold in the bounded select (tests)
     int knob_fused_probe = 1;        // FSPANN_ROUTE_FUSED_PROBE=0: separate probe kernel in front of the bounded select
     int knob_refine_dc = 0;          // FSPANN_REFINE_DC: dims per LDS tile of the refinement scan (tools/refine_bench.py)
-    int knob_refine_stream = 3;      // FSPANN_REFINE_STREAM: workgroups per CU of the streaming refinement scan (0: one workgroup per query)
+    int knob_refine_stream = -1;     // FSPANN_REFINE_STREAM: workgroups per CU of the streaming refinement scan (-1: 4 dense / 3 gather, 0: one workgroup per query)
     int knob_tick_refine = 1;        // FSPANN_TICK_REFINE: refine workgroups per CU inside a tick (each streams several queries)
     int knob_gpu_cut = 1;            // FSPANN_GPU_CUT=0: fspann_build_index cuts the partitions on host threads (std::sort) instead of the GPU radix sort
     int knob_tick_fuse = 1;          // FSPANN_TICK_FUSE=0: fspann_tick_dev always uses the stand-alone kernels

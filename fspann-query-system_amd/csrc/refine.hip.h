@@ -86,6 +86,7 @@ struct RefineArgs {
     int32_t* scored;
     RefinePartial* partial;
     int32_t* partial_cnt;
+    long long* dbg;              // FSPANN_DEBUG_STAMPS builds: [grid][16] wall_clock64 stamps of each workgroup's first unit (else unused)
 };
 
 // Stage C for one 256-row chunk (QSI:298-316): stable rank of the chunk's distances by (fp64 bits, candidate position),
@@ -388,12 +389,17 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     int32_t isrc[GATHER ? VPR : 1];                        // gather: store row of each slot for unit iu (clamped into the store)
     int irows = 1;                                         // dense: rows of unit iu that exist in the block
     auto load_sources = [&](const int64_t u) {
-        const int64_t uu = min(u, nunits - 1);             // past the end: the last unit once more (loaded, never consumed)
+        const int64_t uu = min(u, nunits - 1);             // past the end: addresses of the last unit (never consumed)
         const int64_t qi = uu / nchunks;
         const int r0 = static_cast<int>(uu - qi * nchunks) * kRefRows;
         const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
         irows = rows_here;
         if constexpr (GATHER) {
+            if (u >= nunits) {                                      // past the last unit: every lane re-reads row 0 (one cache line per load)
+#pragma unroll
+                for (int i = 0; i < VPR; i++) isrc[i] = 0;
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < VPR; i++) {
                 const int row = min(slot_row + i * (64 / VPR), rows_here - 1);
@@ -411,27 +417,52 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     };
     const TC* ibase = unit_base(iu);
     load_sources(iu);
+    // Dense blocks are read through a BUFFER resource per unit (base = the unit's first row, extent = its rows): the address
+    // of slot i is one 32-bit lane offset plus a wave-uniform scalar offset (no 64-bit address arithmetic, no address
+    // registers per slot), and a slot beyond the unit's rows is answered with zeros by the range check instead of a clamp.
+    typedef uint32_t fsp_u32x4 __attribute__((ext_vector_type(4)));
+    // Past the last unit the stream keeps issuing (the loads stay unconditional, see below) but the resource's extent is zero:
+    // every such load is out of range and is answered with zeros without touching memory.
+    auto unit_rsrc = [&]() {
+        const int64_t extent = (iu < nunits) ? static_cast<int64_t>(irows) * d * static_cast<int64_t>(sizeof(TC)) : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<TC*>(ibase), 0, static_cast<int>(extent), 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t irsrc = unit_rsrc();
+    const int slot_off = (slot_row * d + slot_col) * static_cast<int>(sizeof(TC));      // byte offset of slot 0 in tile 0
+    const int slot_step = (64 / VPR) * d * static_cast<int>(sizeof(TC));                // bytes from slot i to slot i + 1
 #define FSP_STREAM_ISSUE(REG)                                                                                       \
     do {                                                                                                            \
-        int col_ = it * DC + slot_col;                                                                              \
-        col_ = (col_ < d) ? col_ : 0;                                                                               \
-        _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                           \
-            const int64_t srow_ = GATHER ? static_cast<int64_t>(isrc[GATHER ? i : 0])                               \
-                                         : static_cast<int64_t>(min(slot_row + i * (64 / VPR), irows - 1));         \
-            REG[i] = *reinterpret_cast<const V*>(ibase + srow_ * d + col_);                                         \
+        if constexpr (GATHER) {                                                                                     \
+            int col_ = it * DC + slot_col;                                                                          \
+            col_ = (col_ < d) ? col_ : 0;                                                                           \
+            _Pragma("unroll") for (int i = 0; i < VPR; i++)                                                         \
+                REG[i] = *reinterpret_cast<const V*>(ibase + static_cast<int64_t>(isrc[GATHER ? i : 0]) * d + col_); \
+        } else {                                                                                                    \
+            const int voff_ = slot_off + it * DC * static_cast<int>(sizeof(TC));                                    \
+            _Pragma("unroll") for (int i = 0; i < VPR; i++)                                                         \
+                REG[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(irsrc, voff_, i * slot_step, 0)); \
         }                                                                                                           \
         if (++it == ntile) {                                                                                        \
             it = 0;                                                                                                 \
             iu += nwg;                                                                                              \
             ibase = unit_base(iu);                                                                                  \
             load_sources(iu);                                                                                       \
+            if constexpr (!GATHER) irsrc = unit_rsrc();                                                             \
         }                                                                                                           \
     } while (0)
 #define FSP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+#ifdef FSPANN_DEBUG_STAMPS
+#define RS_STAMP(i) do { if (a.dbg && tid == 0 && first_unit) a.dbg[wg * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
+    bool first_unit = true; (void)first_unit;
+    RS_STAMP(0);
     V regA[VPR], regB[VPR];
     FSP_STREAM_ISSUE(regA);
     FSP_STREAM_ISSUE(regB);
+    RS_STAMP(1);
 
     // ---- consume side ------------------------------------------------------------------------------------------------
     for (int64_t u = wg; u < nunits; u += nwg) {
@@ -487,8 +518,10 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         // tiles of this unit, two per trip: the register sets alternate along the whole stream (A, B, A, B, ...)
         for (int t = 0; t < ntile; t += 2) {
             FSP_STREAM_TILE(regA, t * DC);
+            if (t == 0) RS_STAMP(2);
             if (t + 1 < ntile) {
                 FSP_STREAM_TILE(regB, (t + 1) * DC);
+                if (t == 0) RS_STAMP(3);
             } else {
                 // odd tile count (d not a multiple of 2 DC; none of the BASELINE shapes): the next unit's first tile sits in
                 // set B and its second in set A — exchange them (waits for those loads: correct, just not overlapped)
@@ -496,6 +529,7 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
                 for (int i = 0; i < VPR; i++) { const V tmp = regA[i]; regA[i] = regB[i]; regB[i] = tmp; }
             }
         }
+        RS_STAMP(4);
         const bool qbad = __any(qnf);
         const int cnt = static_cast<int>(min(static_cast<int64_t>(cnt_raw), B));
         const int nrows = max(0, min(kRefRows, cnt - r0));
@@ -504,16 +538,20 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         const bool valid = (tid < nrows) && ok && !qbad;
         uint64_t key = kInvalidKey;
         if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
+        RS_STAMP(5);
         refine_topk_emit<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, chunk, r0);
+        RS_STAMP(6);
         __syncthreads();       // every wave has finished reading the other waves' scratch before the tile is written again
+        first_unit = false;
     }
+#undef RS_STAMP
 #undef FSP_STREAM_TILE
 #undef FSP_STREAM_ISSUE
 #undef FSP_WAVE_SYNC
 }
 
 template <typename TC, typename TQ, int DC, bool GATHER>
-__global__ __launch_bounds__(kRefRows, 2) void refine_stream_kernel(RefineArgs<TC, TQ> a, int64_t nq) {
+__global__ __launch_bounds__(kRefRows, (GATHER ? 2 : 4)) void refine_stream_kernel(RefineArgs<TC, TQ> a, int64_t nq) {
     extern __shared__ __align__(16) unsigned char smem[];
     refine_stream_run<TC, TQ, DC, GATHER>(a, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), nq, false);
 }

@@ -278,6 +278,12 @@ class FspannContext:
         N.check(self.L.fspann_hbm_read_peak(self._h, int(nbytes), int(reps), C.byref(v)))
         return float(v.value)
 
+    def hbm_read_window(self, nbytes=1 << 32, window=134823936, reps=20) -> float:
+        """GB/s of the same pure-load kernel when one launch reads only `window` bytes of cold HBM (average over `reps`)."""
+        v = C.c_double(0.0)
+        N.check(self.L.fspann_hbm_read_window(self._h, int(nbytes), int(window), int(reps), C.byref(v)))
+        return float(v.value)
+
     # -- device-pointer entry points (ints) ----------------------------------------------
     def encode_dev(self, nq, q_ptr, dtype, codes_ptr, hashes_ptr=0, bad_ptr=0):
         N.check(self.L.fspann_encode_dev(self._h, nq, q_ptr, dtype, codes_ptr, hashes_ptr or None, bad_ptr or None))

@@ -355,6 +355,10 @@ int fspann_allgather_topk_dev(fspann_comm* comm, int64_t nq_local, int k, const 
 /* Measurement aid (bench.py roofline.peak_measured): GB/s at which this device streams `bytes` of HBM through a pure
  * 16-byte-load kernel (best of `reps`); pick bytes well above the 256 MiB Infinity Cache.                         */
 int fspann_hbm_read_peak(fspann_ctx* ctx, size_t bytes, int reps, double* gb_per_s);
+/* The same kernel on a launch of the hot path's size: `reps` launches, each reading the next `window` bytes of a `bytes`
+ * buffer (so every launch reads cold HBM), average rate over the launches.  What a short launch can reach at all: the
+ * ramp at the start and the drain at the end of a launch are not amortised over 134 MB as they are over 4 GiB.     */
+int fspann_hbm_read_window(fspann_ctx* ctx, size_t bytes, size_t window, int reps, double* gb_per_s);
 
 /* ---- device memory helpers (so non-torch callers can own HBM buffers) ------------------- */
 int fspann_dev_alloc(fspann_ctx* ctx, size_t bytes, void** out);

@@ -27,6 +27,7 @@ OUT = {
     ("fspann_pipeline_stats", "refine_ms"): "double", ("fspann_pipeline_stats", "batches"): "long",
     ("fspann_comm_info", "world"): "int", ("fspann_comm_info", "rank"): "int",
     ("fspann_hbm_read_peak", "gb_per_s"): "double",
+    ("fspann_hbm_read_window", "gb_per_s"): "double",
 }
 TICK_FIELDS = ["nq_encode", "enc_q_dev", "enc_dtype", "pad0", "enc_codes_dev", "enc_bad_dev", "nq_route", "route_codes_dev",
                "route_probe_override", "route_limit", "route_ids_dev", "route_count_dev", "route_handover_dev", "nq_refine", "ref_q_dev",
