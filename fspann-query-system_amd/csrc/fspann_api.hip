@@ -100,13 +100,52 @@ int upload_index(fspann_ctx* c) {
         t.off_base = offs;
         t.ids_base = ids;
         t.nparts = static_cast<int32_t>(c->h_min[td].size());
+        t.dir_base = 0;
         parts += t.nparts;
         offs += t.nparts + 1;
         ids += static_cast<int64_t>(c->h_ids[td].size());
     }
     c->total_parts = parts;
     c->total_ids = ids;
-    free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
+    free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids); free_devt(c->d_dir);
+    // Radix directory of the probe (route.hip.h, route_probe_table): for every table and every value p of the key's top
+    // dir_bits bits, the first partition with maxKey >= p << s and the first with minKey >= p << s.  It needs what the
+    // reference's own binary search needs, key ranges in ascending order; an imported index without that keeps the plain search.
+    std::vector<int2> dir;
+    c->dir_bits = 0;
+    {
+        int maxp = 0;
+        bool mono = true;
+        for (int td = 0; td < TD && mono; td++) {
+            const auto& mn = c->h_min[td]; const auto& mx = c->h_max[td];
+            maxp = std::max<int>(maxp, static_cast<int>(mn.size()));
+            for (size_t i = 0; i < mn.size() && mono; i++)
+                mono = mn[i] >= 0 && mn[i] <= mx[i] && (i == 0 || (mn[i] >= mn[i - 1] && mx[i] >= mx[i - 1]));
+        }
+        int bits = 1;
+        while (bits < 16 && (4 << bits) < maxp) bits++;      // about four partitions per directory entry
+        bits = std::min(20, std::max(1, bits + c->knob_dir_extra_bits));
+        const size_t D = size_t(1) << bits;
+        if (mono && maxp > 0 && static_cast<size_t>(TD) * (D + 1) < (size_t(1) << 30)) {
+            dir.resize(static_cast<size_t>(TD) * (D + 1));
+            const int sh = 63 - bits;
+            for (int td = 0; td < TD; td++) {
+                const auto& mn = c->h_min[td]; const auto& mx = c->h_max[td];
+                const int np = static_cast<int>(mn.size());
+                c->h_tables[td].dir_base = static_cast<int32_t>(static_cast<size_t>(td) * (D + 1));
+                int2* dd = dir.data() + static_cast<size_t>(td) * (D + 1);
+                int ia = 0, ie = 0;
+                for (size_t pfx = 0; pfx < D; pfx++) {
+                    const int64_t bound = static_cast<int64_t>(pfx) << sh;
+                    while (ia < np && mx[ia] < bound) ia++;
+                    while (ie < np && mn[ie] < bound) ie++;
+                    dd[pfx] = make_int2(ia, ie);
+                }
+                dd[D] = make_int2(np, np);
+            }
+            c->dir_bits = bits;
+        }
+    }
     std::vector<int64_t> keys2(static_cast<size_t>(std::max<int64_t>(parts, 1)) * 2);
     std::vector<uint64_t> rep(static_cast<size_t>(std::max<int64_t>(parts, 1)) * W);
     std::vector<int32_t> off(static_cast<size_t>(offs));
@@ -131,6 +170,10 @@ int upload_index(fspann_ctx* c) {
     FSP_HIP(hipMemcpy(c->d_rep, rep.data(), rep.size() * 8, hipMemcpyHostToDevice));
     if (!off.empty()) FSP_HIP(hipMemcpy(c->d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     FSP_HIP(hipMemcpy(c->d_ids, idv.data(), idv.size() * 4, hipMemcpyHostToDevice));
+    if (!dir.empty()) {
+        FSP_HIP(hipMalloc(&c->d_dir, dir.size() * sizeof(int2)));
+        FSP_HIP(hipMemcpy(c->d_dir, dir.data(), dir.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
     // For the bounded select (route_lazy.hip.h):
     //   inv[td][id]  position of id in table td's id list (a table holding an id twice cannot be inverted: select stays off)
     //   ids_bk       every partition's ids once more, as (id << 32 | bucket field at the initial HashMap capacity),
@@ -476,6 +519,8 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_threads = env_int("FSPANN_ROUTE_THREADS", 512) == 1024 ? 1024 : 512;
         c->knob_lazy_cap = std::max(0, env_int("FSPANN_ROUTE_LAZY_CAP", 0));
         c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
+        c->knob_probe_dir = env_int("FSPANN_ROUTE_DIR", 1) != 0;
+        c->knob_dir_extra_bits = env_int("FSPANN_ROUTE_DIR_EXTRA_BITS", 0);
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
         c->knob_refine_stream = std::min(4, std::max(-1, env_int("FSPANN_REFINE_STREAM", -1)));   // -1: 4 per CU dense, 3 per CU gather
         c->knob_tick_refine = std::min(4, std::max(1, env_int("FSPANN_TICK_REFINE", 1)));
@@ -498,7 +543,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_dev(c->ws_fix.p);
-    free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids);
+    free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids); free_devt(c->d_dir);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits); free_devt(c->d_unmodelled);
     if (c->store_owned) free_dev(c->d_store);
     free_dev(c->ws_tickfix.p); free_dev(c->d_fixparams); free_dev(c->ws_gt.p);
@@ -913,6 +958,7 @@ int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int prob
     if (ar_g + so_g && (rc = ensure(c, c->ws_route, ar_g + so_g + 512))) return rc;
     RouteParams p{};
     p.codes = codes_dev; p.tables = c->d_tables; p.keys2 = c->d_keys2; p.rep = c->d_rep; p.id_off = c->d_off; p.ids = c->d_ids;
+    p.dir = c->knob_probe_dir ? c->d_dir : nullptr; p.dir_bits = c->dir_bits;
     p.java_hash = c->d_java_hash; p.deleted_bits = c->d_deleted_bits;
     p.nq = nq; p.TD = c->TD; p.W = c->W; p.P = pl.P; p.S = pl.S; p.S_shift = pl.S_shift;
     p.hard_cap = c->hard_cap; p.cap0 = c->cap0; p.limit = limit; p.need_cap = pl.need_cap; p.nbins = pl.nbins;

@@ -55,7 +55,7 @@ struct RouteTable {
     int64_t off_base;   // first entry of this table in id_off (nparts+1 entries per table)
     int64_t ids_base;   // first id of this table in ids
     int32_t nparts;
-    int32_t pad;
+    int32_t dir_base;   // first entry pair of this table in the radix directory (RouteParams::dir), in pairs
 };
 
 struct DevBuf {
@@ -85,6 +85,8 @@ struct fspann_ctx {
     int knob_lazy_cap = 0;           // FSPANN_ROUTE_LAZY_CAP: entries one query may hold in the bounded select (tests)
     int knob_fused_probe = 1;        // FSPANN_ROUTE_FUSED_PROBE=0: separate probe kernel in front of the bounded select
     int knob_refine_dc = 0;          // FSPANN_REFINE_DC: dims per LDS tile of the refinement scan (tools/refine_bench.py)
+    int knob_dir_extra_bits = 0;     // FSPANN_ROUTE_DIR_EXTRA_BITS: finer (+) or coarser (-) radix directory than four partitions per entry
+    bool knob_probe_dir = true;      // FSPANN_ROUTE_DIR: radix directory + one-round window in the probe (0: plain G-ary search)
     int knob_refine_stream = -1;     // FSPANN_REFINE_STREAM: workgroups per CU of the streaming refinement scan (-1: 4 dense / 3 gather, 0: one workgroup per query)
     int knob_tick_refine = 1;        // FSPANN_TICK_REFINE: refine workgroups per CU inside a tick (each streams several queries)
     int knob_gpu_cut = 1;            // FSPANN_GPU_CUT=0: fspann_build_index cuts the partitions on host threads (std::sort) instead of the GPU radix sort
@@ -114,6 +116,8 @@ struct fspann_ctx {
     fspann::RouteTable* d_tables = nullptr;
     int64_t* d_keys2 = nullptr;   // [total_parts][2] {min,max}
     uint64_t* d_rep = nullptr;    // [total_parts][W]
+    int2* d_dir = nullptr;        // radix directory of the probe: [TD][2^dir_bits + 1] {first maxKey >= bound, first minKey >= bound}
+    int dir_bits = 0;
     int32_t* d_off = nullptr;     // per table nparts+1 entries, relative to ids_base
     int32_t* d_ids = nullptr;
     int32_t* d_inv = nullptr;        // [TD][n_ids] inverse id map for the bounded select (null: a table holds an id twice)

@@ -420,7 +420,6 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     // Dense blocks are read through a BUFFER resource per unit (base = the unit's first row, extent = its rows): the address
     // of slot i is one 32-bit lane offset plus a wave-uniform scalar offset (no 64-bit address arithmetic, no address
     // registers per slot), and a slot beyond the unit's rows is answered with zeros by the range check instead of a clamp.
-    typedef uint32_t fsp_u32x4 __attribute__((ext_vector_type(4)));
     // Past the last unit the stream keeps issuing (the loads stay unconditional, see below) but the resource's extent is zero:
     // every such load is out of range and is answered with zeros without touching memory.
     auto unit_rsrc = [&]() {

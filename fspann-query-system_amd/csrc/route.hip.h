@@ -43,6 +43,8 @@ struct RouteParams {
     const int64_t* keys2;          // [parts][2] {minKey,maxKey}
     const uint64_t* rep;           // [parts][W]
     const int32_t* id_off;         // per table nparts+1
+    const int2* dir;               // radix directory: per table 2^dir_bits + 1 pairs {first partition with maxKey >= p << s,
+    int dir_bits;                  //   first partition with minKey >= p << s}, s = 63 - dir_bits; null: search from scratch
     const int32_t* ids;
     const int32_t* java_hash;      // [n_ids]
     const uint32_t* deleted_bits;  // may be null
@@ -180,6 +182,51 @@ __device__ __forceinline__ int wave_find_cut(const int32_t* bins, int nb, int ne
     return res_b;
 }
 
+// The best-first expansion of PIS:643-685 for one table, replayed from the group's LDS scratch w3 = [2P-1][3]
+// {Hamming(q, rep), id offset, size} of the partitions center-(P-1) .. center+(P-1).  Every lane of the group runs it (the
+// trip count is group-uniform); lane 0 writes the list.  Returns the number of partitions probed.
+template <typename OutPtr>
+__device__ __forceinline__ int route_probe_replay(const RouteTable& tb, const int P, const int nd, const int center, const int gl,
+                                                  const int32_t* w3, OutPtr po) {
+    // java.util.PriorityQueue with <= 2 live entries: offer() makes the newcomer the root only
+    // if STRICTLY smaller (siftUp); poll() promotes the survivor (siftDown on one element).
+    int np = 0;
+    int h_idx0 = center, h_d0 = w3[(P - 1) * 3];
+    int h_idx1 = 0, h_d1 = 0, hn = 1;
+    int vlo = center, vhi = center;
+    while (hn > 0 && np < P) {
+        const int cur = h_idx0, curd = h_d0;
+        hn--;
+        if (hn == 1) { h_idx0 = h_idx1; h_d0 = h_d1; }
+        if (gl == 0) {
+            const int ci = cur - center + (P - 1);
+            po[np] = make_int4(cur, curd, w3[ci * 3 + 1], w3[ci * 3 + 2]);
+        }
+        np++;
+        const int left = cur - 1;
+        if (left >= 0 && left < vlo) {
+            vlo = left;
+            const int li = left - center + (P - 1);
+            const int dd = (li >= 0 && li < nd) ? w3[li * 3] : 0;  // out of reach: never polled
+            if (hn == 0) { h_idx0 = left; h_d0 = dd; }
+            else if (dd < h_d0) { h_idx1 = h_idx0; h_d1 = h_d0; h_idx0 = left; h_d0 = dd; }
+            else { h_idx1 = left; h_d1 = dd; }
+            hn++;
+        }
+        const int right = cur + 1;
+        if (right < tb.nparts && right > vhi) {
+            vhi = right;
+            const int ri = right - center + (P - 1);
+            const int dd = (ri >= 0 && ri < nd) ? w3[ri * 3] : 0;
+            if (hn == 0) { h_idx0 = right; h_d0 = dd; }
+            else if (dd < h_d0) { h_idx1 = h_idx0; h_d1 = h_d0; h_idx0 = right; h_d0 = dd; }
+            else { h_idx1 = right; h_d1 = dd; }
+            hn++;
+        }
+    }
+    return np;
+}
+
 // ------------------------------------------------------------------------------------------
 // Kernel 1: search + probe order.  One lane group (G lanes) per (query, table).
 // probe_out[(q*TD + td)*P + step] = {partition, Hamming, id_off b0, size}; nprobe_out[q*TD + td].
@@ -194,13 +241,106 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
     const int W = prm.W, P = prm.P;
     const int nd = 2 * P - 1;
     act = act && tb.nparts > 0;
-    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp_in_wave * G));
+    const int gshift = grp_in_wave * G;
+    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gshift);
     // GreedyPartitioner.computeKey: code bit i -> key bit 62-i (i < 63)
     const int64_t qKey = act ? static_cast<int64_t>(__brevll(qc[0]) >> 1) : 0;
     const int64_t* k2 = prm.keys2 + tb.part_base * 2;
+    const uint64_t* repb = prm.rep + tb.part_base * W;
     // a = first partition with maxKey >= qKey ; e = first partition with minKey > qKey.
-    // G-ary search, both at once.  Invariant: answer in [lo, hi], hi == nparts or pred(hi) true.
+    // Invariant of both searches: answer in [lo, hi], hi == nparts or pred(hi) true.
     int loA = 0, hiA = act ? tb.nparts : 0, loE = 0, hiE = hiA;
+    if (prm.dir && act) {
+        // radix directory on the key's top bits: ONE dependent load instead of the first rounds of the search.  Keys are
+        // monotone over the partitions (checked when the directory is built), so for a query key with prefix p
+        // a lies in [A[p], A[p+1]] and e in [E[p], E[p+1]], and the predicate holds at the upper ends (or they are nparts).
+        const int2* dd = prm.dir + tb.dir_base + (qKey >> (63 - prm.dir_bits));
+        const int2 d0 = dd[0], d1 = dd[1];
+        loA = d0.x; hiA = d1.x; loE = d0.y; hiE = d1.y;
+    }
+    // ---- fast path: everything the rest of the probe can need lies in a window of <= 2 G partitions around the answer:
+    // [loA - P, hiE + P - 1] (a - 1 for the gap rule, center in [a - 1, e - 1], P - 1 neighbours either side).  ONE round of
+    // loads fetches key ranges, representative codes and id ranges of the whole window; the searches, the gap rule and the
+    // 2P-1 Hamming distances are then resolved from registers.
+    const int wlo = max(loA - P, 0);
+    const int whi = min(hiE + P - 1, tb.nparts - 1);
+    const bool fits = !act || (whi - wlo + 1 <= 2 * G);
+    if (!__any(!fits)) {
+        int center = 0;
+        {
+            int64_t mn[2] = {0, 0}, mx[2] = {0, 0};
+            int hd[2] = {0, 0}, b0v[2] = {0, 0}, szv[2] = {0, 0};
+            bool val[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int part = wlo + k * G + gl;
+                val[k] = act && part <= whi;
+                if (val[k]) {
+                    const longlong2 kk = *reinterpret_cast<const longlong2*>(k2 + 2 * static_cast<int64_t>(part));
+                    mn[k] = kk.x; mx[k] = kk.y;
+                    hd[k] = ham_words(qc, repb + static_cast<int64_t>(part) * W, W);
+                    const int32_t* off = prm.id_off + tb.off_base + part;
+                    b0v[k] = off[0];
+                    szv[k] = off[1] - b0v[k];
+                }
+            }
+            // first window partition with the predicate true (none: the answer is nparts, see the invariant)
+            auto first_true = [&](bool p0, bool p1) -> int {
+                const unsigned long long m0 = (__ballot(p0) & gmask) >> gshift, m1 = (__ballot(p1) & gmask) >> gshift;
+                if (m0) return wlo + __ffsll(static_cast<long long>(m0)) - 1;
+                if (m1) return wlo + G + __ffsll(static_cast<long long>(m1)) - 1;
+                return tb.nparts;
+            };
+            const int a = first_true(val[0] && mx[0] >= qKey, val[1] && mx[1] >= qKey);
+            const int e = first_true(val[0] && mn[0] > qKey, val[1] && mn[1] > qKey);
+            // value of window partition `part` (group-uniform), held by lane (part - wlo) % G in slot (part - wlo) / G
+            auto fetch64 = [&](const int64_t (&v)[2], int part) -> int64_t {
+                const int rel = min(max(part - wlo, 0), 2 * G - 1);
+                const int64_t mine = (rel >= G) ? v[1] : v[0];
+                const int src = gshift + (rel & (G - 1));
+                const int lo32 = __shfl(static_cast<int>(mine), src), hi32 = __shfl(static_cast<int>(mine >> 32), src);
+                return (static_cast<int64_t>(hi32) << 32) | static_cast<uint32_t>(lo32);
+            };
+            const int64_t lmax = fetch64(mx, a - 1), rmin = fetch64(mn, a);
+            if (act) {
+                const int b = e - 1;
+                if (a <= b) {
+                    // replay findNearestPartition's loop: mid > b <=> qKey < minKey[mid]; mid < a <=> qKey > maxKey[mid]
+                    int lo = 0, hi = tb.nparts - 1;
+                    center = a;
+                    while (lo <= hi) {
+                        const int mid = static_cast<int>((static_cast<unsigned>(lo) + static_cast<unsigned>(hi)) >> 1);
+                        if (mid > b) hi = mid - 1;
+                        else if (mid < a) lo = mid + 1;
+                        else { center = mid; break; }
+                    }
+                } else {
+                    const int lo = a;  // the loop ends with lo = first partition with minKey > qKey
+                    if (lo <= 0) center = 0;
+                    else if (lo >= tb.nparts) center = tb.nparts - 1;
+                    else {
+                        const int64_t dl = qKey - lmax, dr = rmin - qKey;  // distanceToRange
+                        center = (dl <= dr) ? (lo - 1) : lo;
+                    }
+                }
+                // the 2P-1 reachable partitions: window partitions write their own entry, positions outside the table are zero
+                const int first = center - (P - 1);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int l = wlo + k * G + gl - first;
+                    if (val[k] && l >= 0 && l < nd) { w3[l * 3 + 0] = hd[k]; w3[l * 3 + 1] = b0v[k]; w3[l * 3 + 2] = szv[k]; }
+                }
+                for (int l = gl; l < nd; l += G) {
+                    const int part = first + l;
+                    if (part < 0 || part >= tb.nparts) { w3[l * 3 + 0] = 0; w3[l * 3 + 1] = 0; w3[l * 3 + 2] = 0; }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return act ? route_probe_replay(tb, P, nd, center, gl, w3, po) : 0;
+    }
+    // ---- general path: G-ary search, both at once, from the directory's (or the whole table's) bounds
     while (__any((hiA > loA) || (hiE > loE))) {
         const int stA = (hiA - loA + G - 1) / G, stE = (hiE - loE + G - 1) / G;
         const int sA = loA + gl * stA, sE = loE + gl * stE;  // my segment starts
@@ -252,7 +392,6 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
             }
         }
         // one round: Hamming(q, rep) + id range of every partition reachable with P probes
-        const uint64_t* repb = prm.rep + tb.part_base * W;
         for (int l = gl; l < nd; l += G) {
             const int part = center - (P - 1) + l;
             int dd = 0, b0 = 0, sz = 0;
@@ -267,45 +406,7 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int np = 0;
-    if (act) {
-        // java.util.PriorityQueue with <= 2 live entries: offer() makes the newcomer the root only
-        // if STRICTLY smaller (siftUp); poll() promotes the survivor (siftDown on one element).
-        int h_idx0 = center, h_d0 = w3[(P - 1) * 3];
-        int h_idx1 = 0, h_d1 = 0, hn = 1;
-        int vlo = center, vhi = center;
-        while (hn > 0 && np < P) {
-            const int cur = h_idx0, curd = h_d0;
-            hn--;
-            if (hn == 1) { h_idx0 = h_idx1; h_d0 = h_d1; }
-            if (gl == 0) {
-                const int ci = cur - center + (P - 1);
-                po[np] = make_int4(cur, curd, w3[ci * 3 + 1], w3[ci * 3 + 2]);
-            }
-            np++;
-            const int left = cur - 1;
-            if (left >= 0 && left < vlo) {
-                vlo = left;
-                const int li = left - center + (P - 1);
-                const int dd = (li >= 0 && li < nd) ? w3[li * 3] : 0;  // out of reach: never polled
-                if (hn == 0) { h_idx0 = left; h_d0 = dd; }
-                else if (dd < h_d0) { h_idx1 = h_idx0; h_d1 = h_d0; h_idx0 = left; h_d0 = dd; }
-                else { h_idx1 = left; h_d1 = dd; }
-                hn++;
-            }
-            const int right = cur + 1;
-            if (right < tb.nparts && right > vhi) {
-                vhi = right;
-                const int ri = right - center + (P - 1);
-                const int dd = (ri >= 0 && ri < nd) ? w3[ri * 3] : 0;
-                if (hn == 0) { h_idx0 = right; h_d0 = dd; }
-                else if (dd < h_d0) { h_idx1 = h_idx0; h_d1 = h_d0; h_idx0 = right; h_d0 = dd; }
-                else { h_idx1 = right; h_d1 = dd; }
-                hn++;
-            }
-        }
-    }
-    return np;
+    return act ? route_probe_replay(tb, P, nd, center, gl, w3, po) : 0;
 }
 
 __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams prm, int4* __restrict__ probe_out,

@@ -82,10 +82,10 @@ template <int kThreads>
 __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned char* smem, const int64_t q_first, const int64_t q_stride, const int block_id) {
     int4* probe_in = prm.probe_g;          // not __restrict__: a handed-over query's lists are written here and read back
     int32_t* nprobe_in = prm.nprobe_g;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;                      // not const: see the register note behind the probe
     constexpr int nthreads = kThreads;
     constexpr int nwv = kThreads / 64;
-    const int lane = tid & 63, wave = tid >> 6;
+    int lane = tid & 63, wave = tid >> 6;
     const int TD = prm.TD, P = prm.P, S = prm.S;
     const int TP = TD * P;
     const int SP = (S + 63) >> 6;                 // 64-lane pieces per partition
@@ -114,7 +114,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     constexpr uint32_t ht_mask = kLzHtSize - 1;
     constexpr int ht_shift = 32 - 11;
     static_assert(kLzHtSize == 2048, "ht_shift");
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long lt_mask = 0;
 
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
     for (int i = tid; i < kLzHtSize; i += nthreads) ht[i] = kLzEmpty;
@@ -239,6 +239,12 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         if (tid == 0) { s_u = 0; s_R = TP; s_ncoll = 0; s_bad = 0; s_short = 0; pkv[TP] = make_uint2(0xFFFFFFFFu, 0u); }
         __syncthreads();
         LZ_STAMP(1);
+        // Register note: everything below indexes by tid / lane / wave, and the compiler would compute all of those per-thread
+        // offsets ONCE before the query loop and keep them alive through the probe above (its peak: a window of key ranges,
+        // codes and id ranges per lane) — enough to spill.  Redefining the three here (the asm changes nothing) ties every
+        // derived value to this point of the iteration.
+        asm volatile("" : "+v"(tid), "+v"(lane), "+v"(wave));
+        lt_mask = (1ull << lane) - 1ull;
         // ---- 1. order the probed partitions by (distance, Java order); prefix sums of their sizes ----------------
         for (int i = tid; i < TP; i += nthreads) {
             const uint2 me = pkv[i];
