@@ -107,7 +107,7 @@ int upload_index(fspann_ctx* c) {
     }
     c->total_parts = parts;
     c->total_ids = ids;
-    free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids); free_devt(c->d_dir);
+    free_devt(c->d_tables); free_devt(c->d_recs); free_devt(c->d_ids); free_devt(c->d_dir);
     // Radix directory of the probe (route.hip.h, route_probe_table): for every table and every value p of the key's top
     // dir_bits bits, the first partition with maxKey >= p << s and the first with minKey >= p << s.  It needs what the
     // reference's own binary search needs, key ranges in ascending order; an imported index without that keeps the plain search.
@@ -146,29 +146,30 @@ int upload_index(fspann_ctx* c) {
             c->dir_bits = bits;
         }
     }
-    std::vector<int64_t> keys2(static_cast<size_t>(std::max<int64_t>(parts, 1)) * 2);
-    std::vector<uint64_t> rep(static_cast<size_t>(std::max<int64_t>(parts, 1)) * W);
-    std::vector<int32_t> off(static_cast<size_t>(offs));
+    // One RECORD per partition with everything the probe reads about it — {minKey, maxKey, rep[W], id offset | size << 32},
+    // padded to an even number of 8-byte words: the last rounds of the search, the gap rule and the Hamming round then touch
+    // the same one or two cache lines instead of three arrays (the probe is bound by the latency of cold lines).
+    const int rec_words = (3 + W + 1) & ~1;
+    c->rec_words = rec_words;
+    std::vector<int64_t> recs(static_cast<size_t>(std::max<int64_t>(parts, 1)) * rec_words, 0);
     std::vector<int32_t> idv(static_cast<size_t>(std::max<int64_t>(ids, 1)));
     for (int td = 0; td < TD; td++) {
         const RouteTable& t = c->h_tables[td];
         for (int p = 0; p < t.nparts; p++) {
-            keys2[(t.part_base + p) * 2 + 0] = c->h_min[td][p];
-            keys2[(t.part_base + p) * 2 + 1] = c->h_max[td][p];
-            for (int w = 0; w < W; w++) rep[(t.part_base + p) * W + w] = c->h_rep[td][static_cast<size_t>(p) * W + w];
+            int64_t* r = recs.data() + static_cast<size_t>(t.part_base + p) * rec_words;
+            r[0] = c->h_min[td][p];
+            r[1] = c->h_max[td][p];
+            for (int w = 0; w < W; w++) r[2 + w] = static_cast<int64_t>(c->h_rep[td][static_cast<size_t>(p) * W + w]);
+            const uint64_t b0 = static_cast<uint32_t>(c->h_off[td][p]), sz = static_cast<uint32_t>(c->h_off[td][p + 1] - c->h_off[td][p]);
+            r[2 + W] = static_cast<int64_t>(b0 | (sz << 32));
         }
-        for (int p = 0; p <= t.nparts; p++) off[t.off_base + p] = static_cast<int32_t>(c->h_off[td][p]);
         std::copy(c->h_ids[td].begin(), c->h_ids[td].end(), idv.begin() + t.ids_base);
     }
     FSP_HIP(hipMalloc(&c->d_tables, sizeof(RouteTable) * TD));
-    FSP_HIP(hipMalloc(&c->d_keys2, keys2.size() * 8));
-    FSP_HIP(hipMalloc(&c->d_rep, rep.size() * 8));
-    FSP_HIP(hipMalloc(&c->d_off, std::max<size_t>(off.size(), 1) * 4));
+    FSP_HIP(hipMalloc(&c->d_recs, recs.size() * 8));
     FSP_HIP(hipMalloc(&c->d_ids, idv.size() * 4));
     FSP_HIP(hipMemcpy(c->d_tables, c->h_tables.data(), sizeof(RouteTable) * TD, hipMemcpyHostToDevice));
-    FSP_HIP(hipMemcpy(c->d_keys2, keys2.data(), keys2.size() * 8, hipMemcpyHostToDevice));
-    FSP_HIP(hipMemcpy(c->d_rep, rep.data(), rep.size() * 8, hipMemcpyHostToDevice));
-    if (!off.empty()) FSP_HIP(hipMemcpy(c->d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    FSP_HIP(hipMemcpy(c->d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice));
     FSP_HIP(hipMemcpy(c->d_ids, idv.data(), idv.size() * 4, hipMemcpyHostToDevice));
     if (!dir.empty()) {
         FSP_HIP(hipMalloc(&c->d_dir, dir.size() * sizeof(int2)));
@@ -543,7 +544,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_dev(c->ws_fix.p);
-    free_devt(c->d_tables); free_devt(c->d_keys2); free_devt(c->d_rep); free_devt(c->d_off); free_devt(c->d_ids); free_devt(c->d_dir);
+    free_devt(c->d_tables); free_devt(c->d_recs); free_devt(c->d_ids); free_devt(c->d_dir);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits); free_devt(c->d_unmodelled);
     if (c->store_owned) free_dev(c->d_store);
     free_dev(c->ws_tickfix.p); free_dev(c->d_fixparams); free_dev(c->ws_gt.p);
@@ -957,7 +958,7 @@ int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int prob
     const size_t so_g = static_cast<size_t>(pl.grid) * pl.g_sort_stride * 8;
     if (ar_g + so_g && (rc = ensure(c, c->ws_route, ar_g + so_g + 512))) return rc;
     RouteParams p{};
-    p.codes = codes_dev; p.tables = c->d_tables; p.keys2 = c->d_keys2; p.rep = c->d_rep; p.id_off = c->d_off; p.ids = c->d_ids;
+    p.codes = codes_dev; p.tables = c->d_tables; p.recs = c->d_recs; p.rec_words = c->rec_words; p.ids = c->d_ids;
     p.dir = c->knob_probe_dir ? c->d_dir : nullptr; p.dir_bits = c->dir_bits;
     p.java_hash = c->d_java_hash; p.deleted_bits = c->d_deleted_bits;
     p.nq = nq; p.TD = c->TD; p.W = c->W; p.P = pl.P; p.S = pl.S; p.S_shift = pl.S_shift;

@@ -114,11 +114,10 @@ struct fspann_ctx {
     std::vector<char> h_table_set;
     bool dev_index_dirty = true;
     fspann::RouteTable* d_tables = nullptr;
-    int64_t* d_keys2 = nullptr;   // [total_parts][2] {min,max}
-    uint64_t* d_rep = nullptr;    // [total_parts][W]
+    int64_t* d_recs = nullptr;    // [total_parts][rec_words] partition records {minKey, maxKey, rep[W], id offset | size << 32}
+    int rec_words = 0;
     int2* d_dir = nullptr;        // radix directory of the probe: [TD][2^dir_bits + 1] {first maxKey >= bound, first minKey >= bound}
     int dir_bits = 0;
-    int32_t* d_off = nullptr;     // per table nparts+1 entries, relative to ids_base
     int32_t* d_ids = nullptr;
     int32_t* d_inv = nullptr;        // [TD][n_ids] inverse id map for the bounded select (null: a table holds an id twice)
     uint64_t* d_ids_bk = nullptr;    // per partition: (id << 32 | bucket field) sorted by bucket, for the bounded select

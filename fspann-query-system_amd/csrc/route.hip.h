@@ -40,9 +40,8 @@ namespace fspann {
 struct RouteParams {
     const uint64_t* codes;         // [nq][TD][W]
     const RouteTable* tables;      // [TD]
-    const int64_t* keys2;          // [parts][2] {minKey,maxKey}
-    const uint64_t* rep;           // [parts][W]
-    const int32_t* id_off;         // per table nparts+1
+    const int64_t* recs;           // [parts][rec_words] partition records {minKey, maxKey, rep[W], id offset | size << 32}
+    int rec_words;
     const int2* dir;               // radix directory: per table 2^dir_bits + 1 pairs {first partition with maxKey >= p << s,
     int dir_bits;                  //   first partition with minKey >= p << s}, s = 63 - dir_bits; null: search from scratch
     const int32_t* ids;
@@ -245,8 +244,8 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gshift);
     // GreedyPartitioner.computeKey: code bit i -> key bit 62-i (i < 63)
     const int64_t qKey = act ? static_cast<int64_t>(__brevll(qc[0]) >> 1) : 0;
-    const int64_t* k2 = prm.keys2 + tb.part_base * 2;
-    const uint64_t* repb = prm.rep + tb.part_base * W;
+    const int RW = prm.rec_words;
+    const int64_t* recs = prm.recs + tb.part_base * RW;     // this table's partition records
     // a = first partition with maxKey >= qKey ; e = first partition with minKey > qKey.
     // Invariant of both searches: answer in [lo, hi], hi == nparts or pred(hi) true.
     int loA = 0, hiA = act ? tb.nparts : 0, loE = 0, hiE = hiA;
@@ -276,12 +275,13 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
                 const int part = wlo + k * G + gl;
                 val[k] = act && part <= whi;
                 if (val[k]) {
-                    const longlong2 kk = *reinterpret_cast<const longlong2*>(k2 + 2 * static_cast<int64_t>(part));
+                    const int64_t* rec = recs + static_cast<int64_t>(part) * RW;
+                    const longlong2 kk = *reinterpret_cast<const longlong2*>(rec);
                     mn[k] = kk.x; mx[k] = kk.y;
-                    hd[k] = ham_words(qc, repb + static_cast<int64_t>(part) * W, W);
-                    const int32_t* off = prm.id_off + tb.off_base + part;
-                    b0v[k] = off[0];
-                    szv[k] = off[1] - b0v[k];
+                    hd[k] = ham_words(qc, reinterpret_cast<const uint64_t*>(rec + 2), W);
+                    const int64_t os = rec[2 + W];
+                    b0v[k] = static_cast<int32_t>(os);
+                    szv[k] = static_cast<int32_t>(os >> 32);
                 }
             }
             // first window partition with the predicate true (none: the answer is nparts, see the invariant)
@@ -345,8 +345,8 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
         const int stA = (hiA - loA + G - 1) / G, stE = (hiE - loE + G - 1) / G;
         const int sA = loA + gl * stA, sE = loE + gl * stE;  // my segment starts
         bool pA = false, pE = false;
-        if (hiA > loA && sA < hiA) pA = k2[2 * static_cast<int64_t>(min(sA + stA, hiA) - 1) + 1] >= qKey;
-        if (hiE > loE && sE < hiE) pE = k2[2 * static_cast<int64_t>(min(sE + stE, hiE) - 1)] > qKey;
+        if (hiA > loA && sA < hiA) pA = recs[static_cast<int64_t>(min(sA + stA, hiA) - 1) * RW + 1] >= qKey;
+        if (hiE > loE && sE < hiE) pE = recs[static_cast<int64_t>(min(sE + stE, hiE) - 1) * RW] > qKey;
         const unsigned long long bA = __ballot(pA) & gmask, bE = __ballot(pE) & gmask;
         if (hiA > loA) {
             if (bA == 0) loA = hiA;
@@ -385,8 +385,8 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
             if (lo <= 0) center = 0;
             else if (lo >= tb.nparts) center = tb.nparts - 1;
             else {
-                const int64_t lmax = k2[2 * static_cast<int64_t>(lo - 1) + 1];
-                const int64_t rmin = k2[2 * static_cast<int64_t>(lo)];
+                const int64_t lmax = recs[static_cast<int64_t>(lo - 1) * RW + 1];
+                const int64_t rmin = recs[static_cast<int64_t>(lo) * RW];
                 const int64_t dl = qKey - lmax, dr = rmin - qKey;  // distanceToRange
                 center = (dl <= dr) ? (lo - 1) : lo;
             }
@@ -396,10 +396,11 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
             const int part = center - (P - 1) + l;
             int dd = 0, b0 = 0, sz = 0;
             if (part >= 0 && part < tb.nparts) {
-                dd = ham_words(qc, repb + static_cast<int64_t>(part) * W, W);
-                const int32_t* off = prm.id_off + tb.off_base + part;
-                b0 = off[0];
-                sz = off[1] - b0;
+                const int64_t* rec = recs + static_cast<int64_t>(part) * RW;
+                dd = ham_words(qc, reinterpret_cast<const uint64_t*>(rec + 2), W);
+                const int64_t os = rec[2 + W];
+                b0 = static_cast<int32_t>(os);
+                sz = static_cast<int32_t>(os >> 32);
             }
             w3[l * 3 + 0] = dd; w3[l * 3 + 1] = b0; w3[l * 3 + 2] = sz;
         }
