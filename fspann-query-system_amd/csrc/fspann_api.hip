@@ -282,10 +282,15 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
                              codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap};
     // QB queries per block: 8 for bulk coding (index build), 4 for query batches so that
     // a 1024-query batch still fills 256 CUs.
-    if (nq >= 8192) {
-        constexpr int QB = 8;
-        hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
-    } else {
+    bool launched = false;
+    if constexpr (sizeof(TIn) == 4) {       // (8 fp64 query rows per block do not fit the register budget)
+        if (nq >= 8192) {
+            constexpr int QB = 8;
+            hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
+            launched = true;
+        }
+    }
+    if (!launched) {
         constexpr int QB = 4;
         hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
     }

@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -220,7 +221,8 @@ inline int pointstore_encrypt(fspann_pointstore* ps, int64_t h0, int64_t cnt, co
                 std::memcpy(pt.data() + 8 * j, &bits, 8);
             }
             unsigned char* r = ps->rec(h);
-            ps->ver(h)->store(-1, std::memory_order_release);         // being written
+            ps->ver(h)->store(-1, std::memory_order_relaxed);         // being written ...
+            std::atomic_thread_fence(std::memory_order_release);      // ... and the record's bytes change only after that is visible
             const unsigned char* iv = ivs.data() + static_cast<size_t>(i) * kIvBytes;
             const int al = aad_for(aad, sizeof(aad), h, v, dim);
             std::memcpy(r + 4, iv, kIvBytes);
@@ -235,20 +237,33 @@ inline int pointstore_encrypt(fspann_pointstore* ps, int64_t h0, int64_t cnt, co
 inline bool pointstore_open_one(fspann_pointstore* ps, GcmWorker& w, int64_t h, std::vector<unsigned char>& scratch, double* out, int* version_out) {
     const int dim = ps->dim, ctlen = 8 * dim;
     if (h < 0 || h >= ps->n) return false;
-    for (int attempt = 0; attempt < 1000; attempt++) {
+    // A writer holds a record (version word -1) only while it copies ~1 KB, but on an oversubscribed host it can be
+    // descheduled in the middle: the wait is bounded by TIME (2 s), not by a spin count — a reader that gave up after 1000
+    // yields reported a live record as failed (seen once in the 1 M-record rotate + migrate test on a 4-core share).
+    const auto t_start = std::chrono::steady_clock::now();
+    for (long attempt = 0;; attempt++) {
+        if (attempt > 64 && (attempt & 63) == 0 &&
+            std::chrono::steady_clock::now() - t_start > std::chrono::seconds(2)) return false;
         const int v = ps->ver(h)->load(std::memory_order_acquire);
         if (v == 0) return false;                      // never written / deleted: loadPointIfActive() == null
-        if (v < 0) { std::this_thread::yield(); continue; }
+        if (v < 0) {
+            if (attempt < 16) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            continue;
+        }
         if (w.dec_version != v) {     // derivation + the store's key mutex only when the version changes (one batch's worth of life)
             unsigned char key[32];
             if (!ps->key_for(v, key) || !w.set_dec_key(v, key)) return false;        // retired key: the old ciphertext is unreadable by design
         }
         std::memcpy(scratch.data(), ps->rec(h) + 4, kIvBytes + ctlen + kTagBytes);     // snapshot, then re-check the version
-        if (ps->ver(h)->load(std::memory_order_acquire) != v) continue;
+        std::atomic_thread_fence(std::memory_order_acquire);                            // the copy's reads stay ahead of the re-check
+        if (ps->ver(h)->load(std::memory_order_relaxed) != v) continue;
         char aad[96];
         const int al = aad_for(aad, sizeof(aad), h, v, dim);
         unsigned char* pt = scratch.data() + kIvBytes + ctlen + kTagBytes;
-        if (!w.open(scratch.data(), reinterpret_cast<const unsigned char*>(aad), al, scratch.data() + kIvBytes, ctlen, pt)) return false;
+        if (!w.open(scratch.data(), reinterpret_cast<const unsigned char*>(aad), al, scratch.data() + kIvBytes, ctlen, pt)) {
+            if (ps->ver(h)->load(std::memory_order_acquire) != v) continue;             // rewritten since: the snapshot is stale, not corrupt
+            return false;
+        }
         for (int j = 0; j < dim; j++) {                // deserializeVector
             uint64_t bits;
             std::memcpy(&bits, pt + 8 * j, 8);
@@ -258,7 +273,6 @@ inline bool pointstore_open_one(fspann_pointstore* ps, GcmWorker& w, int64_t h, 
         if (version_out) *version_out = v;
         return true;
     }
-    return false;
 }
 
 // QSI stage B, host part, for a batch: every (query, j < count[q]) candidate is loaded + opened; rows that fail are

@@ -443,9 +443,9 @@ __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams 
 template <bool kLds, int kThreads>
 __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsigned char* smem, int block_id, const int4* __restrict__ probe_q,
                                    const int32_t* __restrict__ nprobe_q, const int64_t qi) {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;                       // not const: see the register note at phase C
     constexpr int nthreads = kThreads;
-    const int lane = tid & 63, wave = tid >> 6;
+    int lane = tid & 63, wave = tid >> 6;
     const int TD = prm.TD, P = prm.P, S = prm.S;
     const int TP = TD * P;
 
@@ -715,6 +715,9 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             __syncthreads();
         }
         FSP_STAMP(3);
+        // Register note (as in route_lazy_run): redefining the thread's coordinates here (the asm changes nothing) keeps the
+        // per-thread offsets of the phases below from being computed up front and held through the phases above.
+        asm volatile("" : "+v"(tid), "+v"(lane), "+v"(wave));
 
         // ---- C: order + select -------------------------------------------------------------
         const int n = s_n;
