@@ -53,3 +53,11 @@ for i, nm in enumerate(names):
 for i in range(1, len(names)):
     dt = (a[:, i] - a[:, i - 1]) * TICK
     print("  %-26s <- %-26s med %5.2f  p90 %5.2f  max %5.2f us" % (names[i], names[i - 1], np.median(dt), np.percentile(dt, 90), dt.max()))
+# per XCD (workgroup id mod 8, the dispatcher's round-robin): when its workgroups have consumed their tiles / written their top-K
+full = dbg.cpu().numpy().astype(np.float64)
+for x in range(8):
+    rows = full[x::8]
+    rows = rows[rows[:, 0] > 0]
+    if len(rows):
+        print("XCD %d: tiles consumed med %6.2f max %6.2f | top-K written med %6.2f max %6.2f us" % (
+            x, (np.median(rows[:, 4]) - t0) * TICK, (rows[:, 4].max() - t0) * TICK, (np.median(rows[:, 6]) - t0) * TICK, (rows[:, 6].max() - t0) * TICK))
