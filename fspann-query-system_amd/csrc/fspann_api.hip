@@ -305,11 +305,11 @@ struct RoutePlan {
     int threads;
     int64_t g_sort_stride;
     // bounded select (route_lazy.hip.h)
-    int lazy, lazy_cap, lz_ht_size, lz_grid;
+    int lazy, lazy_cap, lz_ht_size, lz_grid, lz_entries;
     size_t lz_lds_bytes, small_bytes;
 };
 
-int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, RoutePlan& pl, bool want_counters = true) {
+int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, RoutePlan& pl, bool want_counters = true, bool for_tick = false) {
     pl.P = effective_probes(c, probe_override);
     pl.S = c->cfg.block_size;
     pl.S_shift = ((pl.S & (pl.S - 1)) == 0) ? __builtin_ctz(pl.S) : -1;
@@ -354,12 +354,16 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     const bool legal = c->d_inv && c->d_ids_bk && c->bk_epoch == c->meta_epoch && !pl.need_cap && cap_fixed && !want_counters && limit <= 512 && pl.lds_mode;
     if (legal && c->route_mode != 1 && (c->route_mode == 2 || static_cast<int64_t>(limit) * 4 <= mt)) {
         const int cap_env = c->knob_lazy_cap;   // tests: distinct ids one query may hold before it is handed back
-        const size_t lds = static_cast<size_t>(kLzHtSize) * 8 + TP * 16 + 4096 + 4096 + (TP + 2) * 8 + (TP + 1) * 4 + 8 +
-                           static_cast<size_t>(c->TD) * 8 + ((TP * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kLzEntries) * 2 + 4096 + static_cast<size_t>(c->TD) * 4 + 16;
-        if (TP < 32768 && lds <= budget && small <= lds) {   // small <= lds: a handed-over query runs the full select over this LDS
+        // size class: 512 entries (19.6 KB, 6 workgroups per CU) when limit <= 256 and the probe's scratch fits the smaller key
+        // array; the tick kernel keeps the large class (its redo runs the full select over the same LDS)
+        const bool small_cls = c->knob_lazy_small && !for_tick && limit <= 256 && (kLzThreads / 16) * (2 * pl.P - 1) * 12 <= 512 * 4;
+        const int kent = small_cls ? 512 : kLzEntriesMax;
+        const size_t lds = lz_lds_bytes(kent, c->TD, pl.P);
+        if (TP < 32768 && lds <= budget && (small <= lds || !for_tick)) {   // small <= lds: a handed-over query runs the full select over this LDS
             pl.lazy = 1;
-            pl.lazy_cap = (cap_env > 0) ? std::min(cap_env, kLzEntries) : kLzEntries;
-            pl.lz_ht_size = kLzHtSize;
+            pl.lz_entries = kent;
+            pl.lazy_cap = (cap_env > 0) ? std::min(cap_env, kent) : kent;
+            pl.lz_ht_size = lz_ht_size(kent);
             pl.lz_lds_bytes = lds;
             const int lz_per_cu = std::max<int>(1, std::min<int>(8, static_cast<int>(static_cast<size_t>(c->lds_limit) / (lds + 256))));
             pl.lz_grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * lz_per_cu));
@@ -526,6 +530,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_lazy_cap = std::max(0, env_int("FSPANN_ROUTE_LAZY_CAP", 0));
         c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
         c->knob_probe_dir = env_int("FSPANN_ROUTE_DIR", 1) != 0;
+        c->knob_lazy_small = env_int("FSPANN_ROUTE_LAZY_SMALL", 1) != 0;
         c->knob_dir_extra_bits = env_int("FSPANN_ROUTE_DIR_EXTRA_BITS", 0);
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
         c->knob_refine_stream = std::min(4, std::max(-1, env_int("FSPANN_REFINE_STREAM", -1)));   // -1: 4 per CU dense, 3 per CU gather
@@ -947,14 +952,14 @@ namespace {
 // Argument checks + plan + kernel parameters of one Route call (shared by fspann_route_dev and fspann_tick_dev).
 int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit, int64_t cap, int32_t* ids_dev,
                   int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev, int32_t* raw_seen_dev, RoutePlan* plan_out, RouteParams* prm_out,
-                  bool* fused_out) {
+                  bool* fused_out, bool for_tick = false) {
     if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");  // PIS:594
     if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
     if (!codes_dev) return fail(FSPANN_E_STATE, "MSANNP violation: QueryToken missing BitSet codes");  // PIS:602
     if (!ids_dev || !count_dev) return fail(FSPANN_E_NULL, "output buffer is null");
     if (limit <= 0) return fail(FSPANN_E_ARG, "limit must be > 0");
     RoutePlan pl;
-    int rc = plan_route(c, probe_override, nq, limit, pl, kept_dev != nullptr || raw_seen_dev != nullptr);
+    int rc = plan_route(c, probe_override, nq, limit, pl, kept_dev != nullptr || raw_seen_dev != nullptr, for_tick);
     if (rc) return rc;
     const int64_t need = std::min<int64_t>(limit, pl.maxcand);
     if (cap < need) return fail(FSPANN_E_RANGE, "cap %lld < min(limit, worst case) = %lld", (long long)cap, (long long)need);
@@ -1050,12 +1055,16 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     } while (0)
     c->last_route_lazy = pl.lazy;
     if (pl.lazy) {
-        auto lk = route_select_lazy_kernel<kLzThreads>;
-        if (!(c->attr_mask & 16u)) {
-            FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-            c->attr_mask |= 16u;
+        if (pl.lz_entries == 512) {
+            hipLaunchKernelGGL((route_select_lazy_kernel<kLzThreads, 512>), dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
+        } else {
+            auto lk = route_select_lazy_kernel<kLzThreads, kLzEntriesMax>;
+            if (!(c->attr_mask & 16u)) {
+                FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                c->attr_mask |= 16u;
+            }
+            hipLaunchKernelGGL(lk, dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
         }
-        hipLaunchKernelGGL(lk, dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
         FSP_HIP(hipGetLastError());
         // queries the bounded select handed over (none, normally): the full select over the overflow list
         p.qcount = p.ovf_count; p.qlist = p.ovf_list;
@@ -1331,13 +1340,13 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
     bool fusedR = false, fusedX = false;
     if (R) {
         if ((rc = prepare_route(c, t->nq_route, t->route_codes_dev, t->route_probe_override, t->route_limit, t->route_limit, t->route_ids_dev,
-                                nullptr, t->route_count_dev, nullptr, nullptr, &plR, &pR, &fusedR))) return rc;
+                                nullptr, t->route_count_dev, nullptr, nullptr, &plR, &pR, &fusedR, true))) return rc;
         if (t->route_handover_dev) handover_ptrs(c, t->route_handover_dev, t->nq_route, plR.P, &pR.probe_g, &pR.nprobe_g);
     }
     const bool fix = F && t->ref_handover_dev != nullptr;
     if (fix) {
         if ((rc = prepare_route(c, t->nq_refine, t->ref_codes_dev, t->ref_probe_override, static_cast<int32_t>(t->ref_B), t->ref_B, t->ref_ids_dev,
-                                nullptr, t->ref_count_dev, nullptr, nullptr, &plX, &pX, &fusedX))) return rc;
+                                nullptr, t->ref_count_dev, nullptr, nullptr, &plX, &pX, &fusedX, true))) return rc;
         handover_ptrs(c, t->ref_handover_dev, t->nq_refine, plX.P, &pX.probe_g, &pX.nprobe_g);
         // the redo runs with its arena in global memory: one slice (+ sort buffer for degenerate tie groups) per refine workgroup
         const int full_sort = next_pow2(std::max(plX.maxcand, 1));

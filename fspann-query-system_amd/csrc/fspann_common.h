@@ -86,6 +86,7 @@ struct fspann_ctx {
     int knob_fused_probe = 1;        // FSPANN_ROUTE_FUSED_PROBE=0: separate probe kernel in front of the bounded select
     int knob_refine_dc = 0;          // FSPANN_REFINE_DC: dims per LDS tile of the refinement scan (tools/refine_bench.py)
     int knob_dir_extra_bits = 0;     // FSPANN_ROUTE_DIR_EXTRA_BITS: finer (+) or coarser (-) radix directory than four partitions per entry
+    bool knob_lazy_small = true;     // FSPANN_ROUTE_LAZY_SMALL: 512-entry size class of the bounded select for limit <= 256 (0: always 1024)
     bool knob_probe_dir = true;      // FSPANN_ROUTE_DIR: radix directory + one-round window in the probe (0: plain G-ary search)
     int knob_refine_stream = -1;     // FSPANN_REFINE_STREAM: workgroups per CU of the streaming refinement scan (-1: 4 dense / 3 gather, 0: one workgroup per query)
     int knob_tick_refine = 1;        // FSPANN_TICK_REFINE: refine workgroups per CU inside a tick (each streams several queries)

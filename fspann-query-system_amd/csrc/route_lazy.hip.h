@@ -33,10 +33,18 @@ namespace fspann {
 
 constexpr uint64_t kLzEmpty = ~0ull;
 constexpr int kLzThreads = 256;
-constexpr int kLzHtSize = 2048;     // hash slots (64-bit entries): <= kLzEntries live entries, load <= 0.5
-constexpr int kLzEntries = 1024;    // distinct ids one query may hold
-constexpr int kLzSortMax = 896;     // entries the rank pass takes (padding to a multiple of 8 per slice stays < 1024)
+// Two size classes (template parameter kEnt = distinct ids one query may hold before it is handed over): 1024 for limit <= 512,
+// and 512 for limit <= 256 — 19.6 KB of LDS and 6 workgroups per CU instead of 33 KB and 4, so that Route workgroups and the
+// refinement scan's (37 KB, 128 registers each) fit on a CU side by side instead of taking turns.
+constexpr int kLzEntriesMax = 1024;
 constexpr int kLzCollMax = 256;     // entries sharing (score, bucket) with another one
+constexpr int lz_ht_size(int kEnt) { return 2 * kEnt; }          // hash slots (64-bit entries): load <= 0.5
+constexpr int lz_sort_max(int kEnt) { return kEnt - 128; }       // entries the rank pass takes (16 slices padded to multiples of 8 stay < kEnt)
+constexpr size_t lz_lds_bytes(int kEnt, int TD, int P) {         // dynamic LDS of route_lazy_run (host and device agree through this)
+    return static_cast<size_t>(lz_ht_size(kEnt)) * 8 + static_cast<size_t>(TD) * P * 16 + static_cast<size_t>(kEnt) * 4 + 4096 +
+           (static_cast<size_t>(TD) * P + 2) * 8 + (static_cast<size_t>(TD) * P + 1) * 4 + 8 + static_cast<size_t>(TD) * 8 +
+           ((static_cast<size_t>(TD) * P * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kEnt) * 2 * 3 + static_cast<size_t>(TD) * 4 + 16;
+}
 constexpr int kLzStageU = 4;        // probed partitions in flight per wave
 constexpr int kLzKeep = 8;          // partitions of the crossing level one wave keeps in registers
 
@@ -78,7 +86,7 @@ __device__ __forceinline__ int wave_cut1024(const int32_t* bins, int need, int l
 // The bounded select of the queries q_first, q_first + q_stride, ... < prm.nq by ONE workgroup of kThreads threads
 // (`smem` = its dynamic LDS, `block_id` = its slice of the global fallback arena).  Called by route_select_lazy_kernel
 // and by the route role of tick_kernel (tick.hip.h).
-template <int kThreads>
+template <int kThreads, int kEnt = kLzEntriesMax>
 __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned char* smem, const int64_t q_first, const int64_t q_stride, const int block_id) {
     int4* probe_in = prm.probe_g;          // not __restrict__: a handed-over query's lists are written here and read back
     int32_t* nprobe_in = prm.nprobe_g;
@@ -90,10 +98,12 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     const int TP = TD * P;
     const int SP = (S + 63) >> 6;                 // 64-lane pieces per partition
 
+    constexpr int kLzHtSize = lz_ht_size(kEnt), kLzEntries = kEnt, kLzSortMax = lz_sort_max(kEnt);
+    static_assert(kEnt == 512 || kEnt == 1024, "size classes");
     size_t o = 0;
     uint64_t* ht = reinterpret_cast<uint64_t*>(smem + o);        o += static_cast<size_t>(kLzHtSize) * 8;
     int4* plist = reinterpret_cast<int4*>(smem + o);             o += static_cast<size_t>(TP) * 16;
-    uint32_t* pre = reinterpret_cast<uint32_t*>(smem + o);       o += 1024 * 4;          // (score << 20 | bucket) per entry
+    uint32_t* pre = reinterpret_cast<uint32_t*>(smem + o);       o += static_cast<size_t>(kEnt) * 4;   // (score << 20 | bucket) per entry
     int32_t* bins = reinterpret_cast<int32_t*>(smem + o);        o += 1024 * 4;
     uint2* pkv = reinterpret_cast<uint2*>(smem + o);             o += (static_cast<size_t>(TP) + 2) * 8;   // {distance << 16 | probe index, size}, padded to even
     int32_t* pcs = reinterpret_cast<int32_t*>(smem + o);         o += (static_cast<size_t>(TP) + 1) * 4;
@@ -101,8 +111,8 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     int64_t* ids_base = reinterpret_cast<int64_t*>(smem + o);    o += static_cast<size_t>(TD) * 8;
     uint16_t* ord = reinterpret_cast<uint16_t*>(smem + o);       o += (static_cast<size_t>(TP) * 2 + 3) & ~size_t(3);
     uint16_t* ulist = reinterpret_cast<uint16_t*>(smem + o);     o += static_cast<size_t>(kLzEntries) * 2;   // hash slots of the entries
-    uint16_t* rk = reinterpret_cast<uint16_t*>(smem + o);        o += 1024 * 2;   // entries per (score, bucket) rank: > 1 = collision
-    uint16_t* lrank = reinterpret_cast<uint16_t*>(smem + o);     o += 1024 * 2;   // (score, bucket) rank of each entry
+    uint16_t* rk = reinterpret_cast<uint16_t*>(smem + o);        o += static_cast<size_t>(kEnt) * 2;   // entries per (score, bucket) rank: > 1 = collision
+    uint16_t* lrank = reinterpret_cast<uint16_t*>(smem + o);     o += static_cast<size_t>(kEnt) * 2;   // (score, bucket) rank of each entry
     int32_t* nprobe_l = reinterpret_cast<int32_t*>(smem + o);    // [TD] fused probe: partitions probed per table
     // collision records alias the histogram (free once the levels are in): element, prefix rank, id, sequence
     int32_t* c_elem = bins;
@@ -112,8 +122,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 
     __shared__ int s_u, s_R, s_ncoll, s_bad, s_b, s_cnt, s_short;
     constexpr uint32_t ht_mask = kLzHtSize - 1;
-    constexpr int ht_shift = 32 - 11;
-    static_assert(kLzHtSize == 2048, "ht_shift");
+    constexpr int ht_shift = (kEnt == 1024) ? 32 - 11 : 32 - 10;
     unsigned long long lt_mask = 0;
 
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
@@ -448,8 +457,8 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
             const int nout = min(nsel, prm.limit);
             // element i is ranked by `parts` cooperating lanes, each over a slice of the keys.  Rounds: as many elements as
             // lanes allow, then the few left over with more lanes each (257 entries = 256 with one lane + 1 with 16).
-            for (int i = tid; i < 1024; i += nthreads) pre[i] = (i < nsel) ? static_cast<uint32_t>(ht[ulist[i]]) : 0xFFFFFFFFu;
-            for (int i = tid; i < 512; i += nthreads) reinterpret_cast<uint32_t*>(rk)[i] = 0u;
+            for (int i = tid; i < kEnt; i += nthreads) pre[i] = (i < nsel) ? static_cast<uint32_t>(ht[ulist[i]]) : 0xFFFFFFFFu;
+            for (int i = tid; i < kEnt / 2; i += nthreads) reinterpret_cast<uint32_t*>(rk)[i] = 0u;
             __syncthreads();
             LZ_STAMP(4);
             for (int e0 = 0; e0 < nsel;) {
@@ -578,10 +587,10 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 #undef LZ_INSERT
 }
 
-template <int kThreads>
-__global__ __launch_bounds__(kThreads, 4) void route_select_lazy_kernel(RouteParams prm) {
+template <int kThreads, int kEnt>
+__global__ __launch_bounds__(kThreads, (kEnt <= 512 ? 5 : 4)) void route_select_lazy_kernel(RouteParams prm) {
     extern __shared__ __align__(16) unsigned char smem[];
-    route_lazy_run<kThreads>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
+    route_lazy_run<kThreads, kEnt>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
 }
 
 }  // namespace fspann
