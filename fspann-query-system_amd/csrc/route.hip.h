@@ -257,90 +257,10 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
         const int2 d0 = dd[0], d1 = dd[1];
         loA = d0.x; hiA = d1.x; loE = d0.y; hiE = d1.y;
     }
-    // ---- fast path: everything the rest of the probe can need lies in a window of <= 2 G partitions around the answer:
-    // [loA - P, hiE + P - 1] (a - 1 for the gap rule, center in [a - 1, e - 1], P - 1 neighbours either side).  ONE round of
-    // loads fetches key ranges, representative codes and id ranges of the whole window; the searches, the gap rule and the
-    // 2P-1 Hamming distances are then resolved from registers.
-    const int wlo = max(loA - P, 0);
-    const int whi = min(hiE + P - 1, tb.nparts - 1);
-    const bool fits = !act || (whi - wlo + 1 <= 2 * G);
-    if (!__any(!fits)) {
-        int center = 0;
-        {
-            int64_t mn[2] = {0, 0}, mx[2] = {0, 0};
-            int hd[2] = {0, 0}, b0v[2] = {0, 0}, szv[2] = {0, 0};
-            bool val[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int part = wlo + k * G + gl;
-                val[k] = act && part <= whi;
-                if (val[k]) {
-                    const int64_t* rec = recs + static_cast<int64_t>(part) * RW;
-                    const longlong2 kk = *reinterpret_cast<const longlong2*>(rec);
-                    mn[k] = kk.x; mx[k] = kk.y;
-                    hd[k] = ham_words(qc, reinterpret_cast<const uint64_t*>(rec + 2), W);
-                    const int64_t os = rec[2 + W];
-                    b0v[k] = static_cast<int32_t>(os);
-                    szv[k] = static_cast<int32_t>(os >> 32);
-                }
-            }
-            // first window partition with the predicate true (none: the answer is nparts, see the invariant)
-            auto first_true = [&](bool p0, bool p1) -> int {
-                const unsigned long long m0 = (__ballot(p0) & gmask) >> gshift, m1 = (__ballot(p1) & gmask) >> gshift;
-                if (m0) return wlo + __ffsll(static_cast<long long>(m0)) - 1;
-                if (m1) return wlo + G + __ffsll(static_cast<long long>(m1)) - 1;
-                return tb.nparts;
-            };
-            const int a = first_true(val[0] && mx[0] >= qKey, val[1] && mx[1] >= qKey);
-            const int e = first_true(val[0] && mn[0] > qKey, val[1] && mn[1] > qKey);
-            // value of window partition `part` (group-uniform), held by lane (part - wlo) % G in slot (part - wlo) / G
-            auto fetch64 = [&](const int64_t (&v)[2], int part) -> int64_t {
-                const int rel = min(max(part - wlo, 0), 2 * G - 1);
-                const int64_t mine = (rel >= G) ? v[1] : v[0];
-                const int src = gshift + (rel & (G - 1));
-                const int lo32 = __shfl(static_cast<int>(mine), src), hi32 = __shfl(static_cast<int>(mine >> 32), src);
-                return (static_cast<int64_t>(hi32) << 32) | static_cast<uint32_t>(lo32);
-            };
-            const int64_t lmax = fetch64(mx, a - 1), rmin = fetch64(mn, a);
-            if (act) {
-                const int b = e - 1;
-                if (a <= b) {
-                    // replay findNearestPartition's loop: mid > b <=> qKey < minKey[mid]; mid < a <=> qKey > maxKey[mid]
-                    int lo = 0, hi = tb.nparts - 1;
-                    center = a;
-                    while (lo <= hi) {
-                        const int mid = static_cast<int>((static_cast<unsigned>(lo) + static_cast<unsigned>(hi)) >> 1);
-                        if (mid > b) hi = mid - 1;
-                        else if (mid < a) lo = mid + 1;
-                        else { center = mid; break; }
-                    }
-                } else {
-                    const int lo = a;  // the loop ends with lo = first partition with minKey > qKey
-                    if (lo <= 0) center = 0;
-                    else if (lo >= tb.nparts) center = tb.nparts - 1;
-                    else {
-                        const int64_t dl = qKey - lmax, dr = rmin - qKey;  // distanceToRange
-                        center = (dl <= dr) ? (lo - 1) : lo;
-                    }
-                }
-                // the 2P-1 reachable partitions: window partitions write their own entry, positions outside the table are zero
-                const int first = center - (P - 1);
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int l = wlo + k * G + gl - first;
-                    if (val[k] && l >= 0 && l < nd) { w3[l * 3 + 0] = hd[k]; w3[l * 3 + 1] = b0v[k]; w3[l * 3 + 2] = szv[k]; }
-                }
-                for (int l = gl; l < nd; l += G) {
-                    const int part = first + l;
-                    if (part < 0 || part >= tb.nparts) { w3[l * 3 + 0] = 0; w3[l * 3 + 1] = 0; w3[l * 3 + 2] = 0; }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        return act ? route_probe_replay(tb, P, nd, center, gl, w3, po) : 0;
-    }
-    // ---- general path: G-ary search, both at once, from the directory's (or the whole table's) bounds
+    // G-ary search, both at once, from the directory's (or the whole table's) bounds.  (A variant that fetched key ranges, codes
+    // and id ranges of a whole window of <= 32 partitions in one round and resolved everything from registers was measured and
+    // dropped: the brackets are rarely that narrow — LSH keys are skewed — and its 14 extra registers per lane were the
+    // register peak of the bounded select.)
     while (__any((hiA > loA) || (hiE > loE))) {
         const int stA = (hiA - loA + G - 1) / G, stE = (hiE - loE + G - 1) / G;
         const int sA = loA + gl * stA, sE = loE + gl * stE;  // my segment starts

@@ -93,7 +93,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     int tid = threadIdx.x;                      // not const: see the register note behind the probe
     constexpr int nthreads = kThreads;
     constexpr int nwv = kThreads / 64;
-    int lane = tid & 63, wave = tid >> 6;
+    int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: a scalar — what derives from it is scalar work
     const int TD = prm.TD, P = prm.P, S = prm.S;
     const int TP = TD * P;
     const int SP = (S + 63) >> 6;                 // 64-lane pieces per partition
@@ -252,7 +252,8 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         // offsets ONCE before the query loop and keep them alive through the probe above (its peak: a window of key ranges,
         // codes and id ranges per lane) — enough to spill.  Redefining the three here (the asm changes nothing) ties every
         // derived value to this point of the iteration.
-        asm volatile("" : "+v"(tid), "+v"(lane), "+v"(wave));
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         lt_mask = (1ull << lane) - 1ull;
         // ---- 1. order the probed partitions by (distance, Java order); prefix sums of their sizes ----------------
         for (int i = tid; i < TP; i += nthreads) {
@@ -588,7 +589,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 }
 
 template <int kThreads, int kEnt>
-__global__ __launch_bounds__(kThreads, (kEnt <= 512 ? 5 : 4)) void route_select_lazy_kernel(RouteParams prm) {
+__global__ __launch_bounds__(kThreads, (kEnt <= 512 ? 6 : 4)) void route_select_lazy_kernel(RouteParams prm) {
     extern __shared__ __align__(16) unsigned char smem[];
     route_lazy_run<kThreads, kEnt>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
 }
