@@ -22,6 +22,12 @@
 namespace fspann {
 
 constexpr int kRefRows = 256;     // rows (= lanes) per workgroup
+// Cache policy of the dense row stream (aux operand of the buffer loads): 2 = nt.  The rows are read once; streamed with the
+// default policy they sweep Route's working set (id rows, inverse map, partition records: ~200 MB) out of the 256 MiB Infinity
+// Cache every step.
+#ifndef FSPANN_REFINE_LOAD_AUX
+#define FSPANN_REFINE_LOAD_AUX 2
+#endif
 constexpr int kRefCountUnknown = -0x7FFFFFFF;
 constexpr uint64_t kInvalidKey = ~0ull;
 
@@ -265,7 +271,7 @@ __device__ __forceinline__ void refine_scan_block(const RefineArgs<TC, TQ>& a, u
     if constexpr (VEC) {                                                                                           \
         _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                          \
             const int col = (C0) + ((lane + i * 64) % VPR) * VN;                                                   \
-            if (srow[i] >= 0 && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(srow[i]) * d + col); \
+            if (srow[i] >= 0 && col < d) reg[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(base + static_cast<int64_t>(srow[i]) * d + col)); \
         }                                                                                                          \
     }
     double s = 0.0;
@@ -439,11 +445,11 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
             int col_ = it * DC + slot_col;                                                                          \
             col_ = (col_ < d) ? col_ : 0;                                                                           \
             _Pragma("unroll") for (int i = 0; i < VPR; i++)                                                         \
-                REG[i] = *reinterpret_cast<const V*>(ibase + static_cast<int64_t>(isrc[GATHER ? i : 0]) * d + col_); \
+                REG[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(ibase + static_cast<int64_t>(isrc[GATHER ? i : 0]) * d + col_)); \
         } else {                                                                                                    \
             const int voff_ = slot_off + it * DC * static_cast<int>(sizeof(TC));                                    \
             _Pragma("unroll") for (int i = 0; i < VPR; i++)                                                         \
-                REG[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(irsrc, voff_, i * slot_step, 0)); \
+                REG[i] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(irsrc, voff_, i * slot_step, FSPANN_REFINE_LOAD_AUX)); \
         }                                                                                                           \
         if (++it == ntile) {                                                                                        \
             it = 0;                                                                                                 \

@@ -353,7 +353,7 @@ int fspann_comm_info(fspann_comm* comm, int* world, int* rank, const char** libr
 int fspann_allgather_topk_dev(fspann_comm* comm, int64_t nq_local, int k, const void* local_packed_dev, void* gathered_dev);
 
 /* Measurement aid (bench.py roofline.peak_measured): GB/s at which this device streams `bytes` of HBM through a pure
- * 16-byte-load kernel (best of `reps`); pick bytes well above the 256 MiB Infinity Cache.                         */
+ * 16-byte-load kernel (best of `reps`, and of the default and the nt cache policy); pick bytes well above the 256 MiB Infinity Cache. */
 int fspann_hbm_read_peak(fspann_ctx* ctx, size_t bytes, int reps, double* gb_per_s);
 /* The same kernel on a launch of the hot path's size: `reps` launches, each reading the next `window` bytes of a `bytes`
  * buffer (so every launch reads cold HBM), average rate over the launches.  What a short launch can reach at all: the

@@ -37,13 +37,17 @@ def mk(nctx):
     return ctxs, bufs
 
 
-def run(ctxs, bufs, parts, steps):
+def run(ctxs, bufs, parts_all, steps):
+    parts = parts_all
     for c_, b in zip(ctxs, bufs):      # valid codes for a route-only run
         c_.encode_dev(Q, qs[0].data_ptr(), F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())
         c_.sync()
 
+    split = parts.split("|") if "|" in parts else None     # "R|F": context 0 runs only R steps, context 1 only F steps, ...
+
     def step(i):
         c_, b = ctxs[i % len(ctxs)], bufs[i % len(ctxs)]
+        parts = split[(i % len(ctxs)) % len(split)] if split else parts_all
         if "E" in parts:
             c_.encode_dev(Q, qs[i % NB].data_ptr(), F32, b["codes"].data_ptr(), 0, b["bad"].data_ptr())
         if "R" in parts:
@@ -61,7 +65,7 @@ def run(ctxs, bufs, parts, steps):
     return (time.perf_counter() - t0) / steps * 1e6
 
 
-for nctx in (1, 2, 3, 4):
+for nctx in [int(x) for x in os.environ.get("NCTXS", "1,2,3,4").split(",")]:
     ctxs, bufs = mk(nctx)
     line = []
     for parts in os.environ.get("PARTS", "E,R,F,ER,RF,ERF").split(","):
