@@ -952,7 +952,7 @@ namespace {
 // Argument checks + plan + kernel parameters of one Route call (shared by fspann_route_dev and fspann_tick_dev).
 int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit, int64_t cap, int32_t* ids_dev,
                   int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev, int32_t* raw_seen_dev, RoutePlan* plan_out, RouteParams* prm_out,
-                  bool* fused_out, bool for_tick = false) {
+                  bool* fused_out, bool for_tick = false, bool launches_lazy = true) {
     if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");  // PIS:594
     if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
     if (!codes_dev) return fail(FSPANN_E_STATE, "MSANNP violation: QueryToken missing BitSet codes");  // PIS:602
@@ -996,7 +996,11 @@ int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int prob
             FSP_HIP(hipMemsetAsync(c->ws_ovf.p, 0, 256, c->stream));
             c->ovf_gen_seen = c->ws_ovf.gen;
         }
-        c->ovf_flip ^= 1;
+        // The overflow counters alternate: the bounded select of THIS call counts in one and zeroes the other for the next
+        // call.  Only a call that really launches a bounded select may take its turn — parameters prepared for a redo
+        // (tick: the full select of PENDING queries) leave the turn alone, or the next call would start on a counter
+        // nobody zeroed and hand its full select a list with another batch's queries in front.
+        if (launches_lazy) c->ovf_flip ^= 1;
         p.inv = c->d_inv; p.ids_bk = c->d_ids_bk; p.n_ids = c->n_ids; p.lazy_cap = pl.lazy_cap; p.lz_ht_size = pl.lz_ht_size;
         p.lz_ht_shift = 32 - __builtin_ctz(pl.lz_ht_size);
         p.ovf_count = static_cast<int32_t*>(c->ws_ovf.p) + 16 * c->ovf_flip;          // this call's counter ...
@@ -1346,7 +1350,7 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
     const bool fix = F && t->ref_handover_dev != nullptr;
     if (fix) {
         if ((rc = prepare_route(c, t->nq_refine, t->ref_codes_dev, t->ref_probe_override, static_cast<int32_t>(t->ref_B), t->ref_B, t->ref_ids_dev,
-                                nullptr, t->ref_count_dev, nullptr, nullptr, &plX, &pX, &fusedX, true))) return rc;
+                                nullptr, t->ref_count_dev, nullptr, nullptr, &plX, &pX, &fusedX, true, false))) return rc;
         handover_ptrs(c, t->ref_handover_dev, t->nq_refine, plX.P, &pX.probe_g, &pX.nprobe_g);
         // the redo runs with its arena in global memory: one slice (+ sort buffer for degenerate tie groups) per refine workgroup
         const int full_sort = next_pow2(std::max(plX.maxcand, 1));

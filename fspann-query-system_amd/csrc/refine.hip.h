@@ -271,7 +271,7 @@ __device__ __forceinline__ void refine_scan_block(const RefineArgs<TC, TQ>& a, u
     if constexpr (VEC) {                                                                                           \
         _Pragma("unroll") for (int i = 0; i < VPR; i++) {                                                          \
             const int col = (C0) + ((lane + i * 64) % VPR) * VN;                                                   \
-            if (srow[i] >= 0 && col < d) reg[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(base + static_cast<int64_t>(srow[i]) * d + col)); \
+            if (srow[i] >= 0 && col < d) reg[i] = *reinterpret_cast<const V*>(base + static_cast<int64_t>(srow[i]) * d + col); \
         }                                                                                                          \
     }
     double s = 0.0;

@@ -45,8 +45,11 @@ constexpr size_t lz_lds_bytes(int kEnt, int TD, int P) {         // dynamic LDS 
            (static_cast<size_t>(TD) * P + 2) * 8 + (static_cast<size_t>(TD) * P + 1) * 4 + 8 + static_cast<size_t>(TD) * 8 +
            ((static_cast<size_t>(TD) * P * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kEnt) * 2 * 3 + static_cast<size_t>(TD) * 4 + 16;
 }
-constexpr int kLzStageU = 4;        // probed partitions in flight per wave
-constexpr int kLzKeep = 8;          // partitions of the crossing level one wave keeps in registers
+// probed partitions in flight per wave (lz_stage_u) and partitions of the crossing level one wave keeps in registers (lz_keep).
+// (Halving both fits the small class into 64 registers = 8 workgroups per CU, but a lone launch then takes 52 us instead of 42
+// and three overlapped ones gain nothing: measured, not used.)
+constexpr int lz_stage_u(int) { return 4; }
+constexpr int lz_keep(int) { return 8; }
 
 // wave_find_cut for exactly 1024 bins starting at a 16-byte aligned address: each lane takes 16 bins with four
 // 16-byte reads and walks ITS bins out of registers (no second LDS pass).  One wave; result in every lane.
@@ -99,6 +102,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     const int SP = (S + 63) >> 6;                 // 64-lane pieces per partition
 
     constexpr int kLzHtSize = lz_ht_size(kEnt), kLzEntries = kEnt, kLzSortMax = lz_sort_max(kEnt);
+    constexpr int kLzStageU = lz_stage_u(kEnt), kLzKeep = lz_keep(kEnt);
     static_assert(kEnt == 512 || kEnt == 1024, "size classes");
     size_t o = 0;
     uint64_t* ht = reinterpret_cast<uint64_t*>(smem + o);        o += static_cast<size_t>(kLzHtSize) * 8;

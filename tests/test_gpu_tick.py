@@ -95,7 +95,9 @@ def _check(sc, Qb, out):
         assert not ref["metrics"][:, 4].any()
         assert np.array_equal(res["sel_count"], ref["sel_count"]), b
         assert np.array_equal(np.where(np.arange(B)[None] < res["sel_count"][:, None], res["sel"], -1), ref["sel"][:, :B]), b
-        assert np.array_equal(res["ids"], ref["ids"]) and np.array_equal(res["dist"], ref["dist"]), b
+        wrong = np.where((res["ids"] != ref["ids"]).any(axis=1) | (res["dist"] != ref["dist"]).any(axis=1))[0]
+        assert len(wrong) == 0, (b, wrong[:8].tolist(), [(res["ids"][q][:4].tolist(), ref["ids"][q][:4].tolist(), int(res["scored"][q]),
+                                                           int(ref["metrics"][q, 2]), int(res["count"][q])) for q in wrong[:3]])
         assert np.array_equal(res["count"], ref["count"]) and np.array_equal(res["scored"], ref["metrics"][:, 2])
         assert not res["bad"].any()
     assert not o.unmodelled
