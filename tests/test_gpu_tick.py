@@ -191,3 +191,46 @@ def test_tick_partial_parts_and_errors(pkg, oracle):
         with pytest.raises(pkg.FspannArgumentError, match="go together"):
             ctx.tick_dev(refine=dict(nq=32, q=qd.data_ptr(), B=64, ids=codes.data_ptr(), count=codes.data_ptr(), k=5, out_ids=codes.data_ptr(),
                                      out_dist=codes.data_ptr(), out_count=codes.data_ptr(), cand=qd.data_ptr(), codes=codes.data_ptr()))
+
+
+def test_route_after_a_tick_with_handed_over_queries(pkg, oracle, monkeypatch):
+    """Regression: a tick's Route part hands queries over (they stay PENDING in the batch's hand-over buffer, the overflow list of
+    that launch is never consumed) and the tick's Refine part prepares redo parameters.  A stand-alone fspann_route on the same
+    context right after must start from an empty overflow list: it used to inherit the tick's list and ran the full select for
+    another batch's query numbers over stale probe lists, overwriting correct results."""
+    import torch
+    monkeypatch.setenv("FSPANN_ROUTE_LAZY_CAP", "258")
+    sc = make_scene(oracle, n=40000, d=16, T=10, D=1, m=12, lam=2, B=256, seed=23)
+    o, p = sc["oracle"], sc["params"]
+    B, TD = p["B"], p["T"]
+    dev = torch.device("cuda", 0)
+    F32 = pkg._native.F32
+    Qs = sc["rng"].standard_normal((3, 96, 16)).astype(np.float32)
+    with _ctx(pkg, sc) as ctx:
+        ctx.build_index(sc["X"])
+        ctx.store_set(sc["X"])
+        codes = [ctx.encode(q) for q in Qs]
+        ctx.route(codes[2], limit=B, counters=False)                         # leaves batch C's probe lists in the workspace
+        cd = [torch.from_numpy(c.view(np.int64)).to(dev) for c in codes]
+        sel = torch.full((96, B), -1, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(96, dtype=torch.int32, device=dev)
+        hov = torch.zeros(ctx.route_handover_bytes(96), dtype=torch.uint8, device=dev)
+        oi = torch.zeros((96, K), dtype=torch.int32, device=dev)
+        od = torch.zeros((96, K), dtype=torch.float64, device=dev)
+        oc = torch.zeros(96, dtype=torch.int32, device=dev)
+        qd = torch.from_numpy(Qs[0]).to(dev)
+        route = dict(nq=96, codes=cd[0].data_ptr(), limit=B, ids=sel.data_ptr(), count=cnt.data_ptr(), handover=hov.data_ptr())
+        ctx.tick_dev(None, route, None)                                      # Route of batch A: some queries PENDING
+        ctx.sync()
+        assert (cnt.cpu().numpy() == -2).any()
+        refine = dict(nq=96, q=qd.data_ptr(), B=B, ids=sel.data_ptr(), count=cnt.data_ptr(), k=K, out_ids=oi.data_ptr(), out_dist=od.data_ptr(),
+                      out_count=oc.data_ptr(), codes=cd[0].data_ptr(), handover=hov.data_ptr())
+        ctx.tick_dev(None, route, refine)                                    # Route again + Refine with the redo of A's PENDING queries
+        ctx.sync()
+        ref_a = o.search(Qs[0].astype(np.float64), K)
+        assert np.array_equal(oi.cpu().numpy(), ref_a["ids"]) and np.array_equal(od.cpu().numpy(), ref_a["dist"])
+        for b in (1, 2, 1):                                                  # stand-alone calls behind the ticks
+            got = ctx.route(codes[b], limit=B, counters=False)
+            ref = o.search(Qs[b].astype(np.float64), K)
+            assert np.array_equal(got["count"], ref["sel_count"]), b
+            assert np.array_equal(np.where(np.arange(B)[None] < got["count"][:, None], got["ids"][:, :B], -1), ref["sel"][:, :B]), b
