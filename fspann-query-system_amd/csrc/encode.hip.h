@@ -43,6 +43,7 @@ struct EncodeArgs {
     double* proj;
     const unsigned long long* only_if_over;   // fallback launch behind the MFMA path: runs only when its re-check list overflowed
     unsigned long long over_cap;
+    long long* dbg;                            // FSPANN_DEBUG_STAMPS builds: [grid][16] wall_clock64 stamps per workgroup (else unused)
 };
 
 // One workgroup (kEncThreads threads): QB query vectors x tdPerBlock tables; block (bx, by) of ceil(nq / QB) x ceil(TD / tdPerBlock).
@@ -60,6 +61,12 @@ __device__ __forceinline__ void encode_exact_block(const EncodeArgs<TIn>& a, con
     int32_t* __restrict__ bad = a.bad;
     double* __restrict__ proj = a.proj;
     if (a.only_if_over && *a.only_if_over <= a.over_cap) return;
+#ifdef FSPANN_DEBUG_STAMPS
+#define ENC_STAMP(i, dep) do { if (a.dbg && threadIdx.x == 0 && by == 0 && (dep) != -0x7654321) a.dbg[bx * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define ENC_STAMP(i, dep) do { } while (0)
+#endif
+    ENC_STAMP(0, 0);
     int32_t* Hs = lds;                       // [QB * kEncThreads]
     int* badq = lds + QB * kEncThreads;      // [QB]
 
@@ -97,6 +104,7 @@ __device__ __forceinline__ void encode_exact_block(const EncodeArgs<TIn>& a, con
     const_row_t qrow[QB];
 #pragma unroll
     for (int qq = 0; qq < QB; qq++) qrow[qq] = (const_row_t)(q + min(q0 + qq, nq - 1) * d);   // rows past nq: computed, never stored
+    ENC_STAMP(1, 0);
     if (active) {
         // alpha_j is streamed eight dimensions at a time, the NEXT eight requested before the current eight are used, and a
         // scheduling barrier keeps the compiler from sinking the loads to their uses (inside tick_kernel, whose route role
@@ -137,8 +145,10 @@ __device__ __forceinline__ void encode_exact_block(const EncodeArgs<TIn>& a, con
 
     // (no LDS store ahead of the projection loop: with one, the loop's query loads stop being scalar loads and every
     // alpha load waits for the previous one — measured 41 us per workgroup instead of 12 inside tick_kernel)
+    ENC_STAMP(2, static_cast<int>(acc[0]));        // projection loop done
     if (tid < QB) badq[tid] = 0;
     __syncthreads();                                  // badq[] is zero
+    ENC_STAMP(3, 0);
 #pragma unroll
     for (int u = 0; u < kChk; u++) {
         const int idx = tid + u * kEncThreads;
@@ -162,6 +172,7 @@ __device__ __forceinline__ void encode_exact_block(const EncodeArgs<TIn>& a, con
         }
     }
     __syncthreads();
+    ENC_STAMP(4, 0);                                  // hashes in LDS
 
     // Coding.C: bit pos = (lambda-1-i)*m + j  <-  bit i of (h_j ^ 0x80000000)
     const int bitsTotal = m * lambda;
@@ -206,6 +217,8 @@ __device__ __forceinline__ void encode_exact_block(const EncodeArgs<TIn>& a, con
         }
     }
     if (bad && by == 0 && tid < QB && q0 + tid < nq) bad[q0 + tid] = badq[tid];
+    ENC_STAMP(5, 0);
+#undef ENC_STAMP
 }
 
 template <typename TIn, int QB>

@@ -279,7 +279,7 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
     const int tdPerBlock = std::max(1, kEncThreads / m);
     const int gy = (c->TD + tdPerBlock - 1) / tdPerBlock;
     const EncodeArgs<TIn> ea{q_dev, nq, c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD, tdPerBlock,
-                             codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap};
+                             codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap, c->dbg_route};
     // QB queries per block: 8 for bulk coding (index build), 4 for query batches so that
     // a 1024-query batch still fills 256 CUs.
     bool launched = false;
@@ -291,6 +291,9 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
         }
     }
     if (!launched) {
+        // 4 rows per workgroup = 256 workgroups for a 1024-query batch.  Every workgroup reads all of alpha (256 KB) from L2:
+        // fewer rows per workgroup (2: 12.8 us, 1: 20 us) cost more in that traffic than the extra waves per SIMD buy, and the
+        // loop itself is bound by one dependent fp64 instruction per ~10 cycles of a lone wave (7.8 of 11.4 us, tools/encode_stamps.py).
         constexpr int QB = 4;
         hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
     }
