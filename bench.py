@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch queries per GPU per step; strong: ONE batch of the workload's size cut into contiguous shards")
     ap.add_argument("--merge", default="inline", choices=["inline", "off"], help="N > 1: all-gather of the top-k behind Refine, same stream")
+    ap.add_argument("--merge-every", type=int, default=4,
+                    help="N > 1: a context gathers the top-k of this many of its batches with ONE collective (bigger, fewer collectives; "
+                         "1 = one per batch); every batch of the timed region is gathered inside it")
     ap.add_argument("--route-counters", action="store_true", help="also produce lastCandKept / rawSeen (forces the full select)")
     ap.add_argument("--host-threads", type=int, default=16, help="host threads of the end-to-end pipeline's AES-GCM pool (0: every core this process may use)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (each with its own HIP stream) per GPU for --pipeline concurrent")
@@ -215,15 +218,17 @@ def main():
     # ---------------- device buffers -------------------------------------------------------------------------------------
     q_all = torch.from_numpy(Qall).to(dev)
 
+    MG = max(1, args.merge_every) if use_dist else 1      # batches of one context per collective (packed buffers hold MG batches)
+
     def mkbufs():
         return dict(codes=torch.zeros((Q, TD, W), dtype=torch.int64, device=dev), bad=torch.zeros(Q, dtype=torch.int32, device=dev),
                     sel_ids=torch.full((Q, B), -1, dtype=torch.int32, device=dev), sel_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
                     kept=torch.zeros(Q, dtype=torch.int32, device=dev), raw=torch.zeros(Q, dtype=torch.int32, device=dev),
                     cand=torch.zeros((Q, B, d), dtype=torch.float32, device=dev) if args.candidates == "gather" or extras else None,
                     # packed (ids | distances) results, double-buffered; the merge is a single collective on them
-                    topk=[fdist.TopkBuffer(Q, k, dev) for _ in range(2)],
+                    topk=[fdist.TopkBuffer(Q * MG, k, dev) for _ in range(2)],
                     out_cnt=torch.zeros(Q, dtype=torch.int32, device=dev), scored=torch.zeros(Q, dtype=torch.int32, device=dev),
-                    gathered=[fdist.GatheredTopk(world, Q, k, dev) for _ in range(2)] if use_dist else None, nsteps=0,
+                    gathered=[fdist.GatheredTopk(world, Q * MG, k, dev) for _ in range(2)] if use_dist else None, nsteps=0,
                     # tick pipeline: three batches in flight, each with its codes, F_q and the hand-over buffer of its Route
                     slot=[dict(codes=torch.zeros((Q, TD, W), dtype=torch.int64, device=dev), bad=torch.zeros(Q, dtype=torch.int32, device=dev),
                                sel_ids=torch.full((Q, B), -1, dtype=torch.int32, device=dev), sel_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
@@ -260,12 +265,21 @@ def main():
         # bootstrapped over the torch group; all ranks fall back to torch.distributed together if any of them cannot
         comms = [fdist.LibComm(c_, world, rank, dev) for c_ in ctxs]
         lib_ok = all(cm.ok for cm in comms)
-        gather_path = (f"fspann_allgather_topk_dev (ncclAllGather via {os.path.basename(comms[0].library)}) on each context's stream"
+        gather_path = (f"fspann_allgather_topk_dev (ncclAllGather via {os.path.basename(comms[0].library)}) on each context's stream, "
+                       f"one collective per {MG} batches of a context"
                        if lib_ok else "torch.distributed all_gather_into_tensor")
 
-    def merge(b, par, stream, si=0):
-        """the ONE collective of the path, behind Refine on the same stream"""
-        if comms is None:
+    def out_slot(b):
+        """packed top-k destination of the context's next batch: (parity, ids pointer, distances pointer, last batch of its group)"""
+        n = b["nsteps"]
+        b["nsteps"] += 1
+        par, slot = (n // MG) & 1, n % MG
+        tk = b["topk"][par]
+        return par, tk.ids.data_ptr() + slot * Q * k * 4, tk.dist.data_ptr() + slot * Q * k * 8, slot == MG - 1
+
+    def merge(b, par, stream, si=0, last=True):
+        """the ONE collective of the path, behind Refine on the same stream: the top-k of the context's last MG batches at once"""
+        if comms is None or not last:
             return
         if comms[si].ok:
             comms[si].allgather_topk(b["topk"][par], b["gathered"][par])
@@ -286,18 +300,16 @@ def main():
         step_no[0] += 1
         qp = q_all[bi].data_ptr()
         cx, stream, b = ctxs[si], streams[si], bufs[si]
-        par = b["nsteps"] & 1
-        b["nsteps"] += 1
-        tk = b["topk"][par]
+        par, ids_p, dist_p, last = out_slot(b)
         if mode == "store" and events is None and not args.route_counters:
             # the whole step in ONE library call (encode -> bounded select -> refine from the store, stream order)
             for pov in probe_passes:
-                cx.search_store_dev(Q, qp, F32, pov, B, k, tk.ids.data_ptr(), tk.dist.data_ptr(), b["out_cnt"].data_ptr(),
+                cx.search_store_dev(Q, qp, F32, pov, B, k, ids_p, dist_p, b["out_cnt"].data_ptr(),
                                     b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), b["bad"].data_ptr())
-            merge(b, par, stream, si)
+            merge(b, par, stream, si, last)
             return
         for pov in probe_passes[:-1]:   # first pass of the adaptive retry (see probe_passes); the stages below are the last pass
-            cx.search_store_dev(Q, qp, F32, pov, B, k, tk.ids.data_ptr(), tk.dist.data_ptr(), b["out_cnt"].data_ptr(),
+            cx.search_store_dev(Q, qp, F32, pov, B, k, ids_p, dist_p, b["out_cnt"].data_ptr(),
                                 b["scored"].data_ptr(), b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), b["bad"].data_ptr())
         if events is not None:
             events[0].record(stream)
@@ -315,15 +327,24 @@ def main():
         if events is not None:
             events[3].record(stream)
         if mode == "store":
-            cx.refine_store_dev(Q, qp, F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k, tk.ids.data_ptr(), tk.dist.data_ptr(),
+            cx.refine_store_dev(Q, qp, F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k, ids_p, dist_p,
                                 b["out_cnt"].data_ptr(), b["scored"].data_ptr())
         else:
             cp = b["cand"].data_ptr() if mode == "gather" else cand_all[bi].data_ptr()
-            cx.refine_dev(Q, qp, F32, cp, F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k, tk.ids.data_ptr(), tk.dist.data_ptr(),
+            cx.refine_dev(Q, qp, F32, cp, F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k, ids_p, dist_p,
                           b["out_cnt"].data_ptr(), b["scored"].data_ptr())
         if events is not None:
             events[4].record(stream)
-        merge(b, par, stream, si)
+        merge(b, par, stream, si, last)
+
+    def flush(nact=1):
+        """gather the batches of a group that is not full yet (end of a timed region: every batch of it is gathered inside it)"""
+        if comms is None or MG == 1:
+            return
+        for si in range(nact):
+            n = bufs[si]["nsteps"]
+            if n % MG != 0:
+                merge(bufs[si], (n // MG) & 1, streams[si], si, True)
 
     def tick(mode, unfused=False):
         """One step of the 3-deep pipeline on context 0: encode(batch t+2), Route(batch t+1), Refine(batch t) — ONE launch.
@@ -334,14 +355,13 @@ def main():
         b["tick_no"] += 1
         bE, bR, bF = (t + 2) % NB, (t + 1) % NB, t % NB
         sE, sR, sF = b["slot"][(t + 2) % 3], b["slot"][(t + 1) % 3], b["slot"][t % 3]
-        par = t & 1
-        tk = b["topk"][par]
+        par, ids_p, dist_p, last = out_slot(b)
         pov = probe_passes[-1]
         if unfused:
             cx.refine_dev(Q, q_all[bF].data_ptr(), F32, cand_all[bF].data_ptr(), F32, B, sF["sel_ids"].data_ptr(), sF["sel_cnt"].data_ptr(), k,
-                          tk.ids.data_ptr(), tk.dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr()) if mode == "dense" else \
-                cx.refine_store_dev(Q, q_all[bF].data_ptr(), F32, B, sF["sel_ids"].data_ptr(), sF["sel_cnt"].data_ptr(), k, tk.ids.data_ptr(),
-                                    tk.dist.data_ptr(), b["out_cnt"].data_ptr(), b["scored"].data_ptr())
+                          ids_p, dist_p, b["out_cnt"].data_ptr(), b["scored"].data_ptr()) if mode == "dense" else \
+                cx.refine_store_dev(Q, q_all[bF].data_ptr(), F32, B, sF["sel_ids"].data_ptr(), sF["sel_cnt"].data_ptr(), k, ids_p,
+                                    dist_p, b["out_cnt"].data_ptr(), b["scored"].data_ptr())
             cx.route_dev(Q, sR["codes"].data_ptr(), pov, B, B, sR["sel_ids"].data_ptr(), 0, sR["sel_cnt"].data_ptr(), 0, 0)
             cx.encode_dev(Q, q_all[bE].data_ptr(), F32, sE["codes"].data_ptr(), 0, sE["bad"].data_ptr())
         else:
@@ -351,9 +371,9 @@ def main():
                            count=sR["sel_cnt"].data_ptr(), handover=sR["hov"].data_ptr()),
                 refine=dict(nq=Q, q=q_all[bF].data_ptr(), B=B, ids=sF["sel_ids"].data_ptr(), count=sF["sel_cnt"].data_ptr(), k=k,
                             cand=cand_all[bF].data_ptr() if mode == "dense" else None, codes=sF["codes"].data_ptr(), handover=sF["hov"].data_ptr(),
-                            probe_override=pov, out_ids=tk.ids.data_ptr(), out_dist=tk.dist.data_ptr(), out_count=b["out_cnt"].data_ptr(),
+                            probe_override=pov, out_ids=ids_p, out_dist=dist_p, out_count=b["out_cnt"].data_ptr(),
                             scored=b["scored"].data_ptr()))
-        merge(b, par, stream)
+        merge(b, par, stream, 0, last)
 
     def tick_prime():
         """fill the pipeline (untimed): encode of batches 0 and 1, Route of batch 0"""
@@ -375,6 +395,7 @@ def main():
         t_s = time.perf_counter()
         for i in range(steps):
             tick(mode, unfused=with_events and (i % every) == every - 1)
+        flush(1)
         ctxs[0].sync()
         torch.cuda.synchronize()
         if use_dist:
@@ -425,6 +446,7 @@ def main():
                 solo_n, solo_ms = solo_n + n_, solo_ms + ms_
             else:
                 step(mode)
+        flush(nact)
         for c_ in ctxs[:nact]:
             c_.sync()
         torch.cuda.synchronize()
@@ -552,8 +574,9 @@ def main():
         tick(mode)
     else:
         step(mode, batch=0)   # (active[0] == 1: context 0)
+    flush(1)
     barrier()
-    out_ids, out_dist = bufs[0]["topk"][0].ids, bufs[0]["topk"][0].dist
+    out_ids, out_dist = bufs[0]["topk"][0].ids[:Q], bufs[0]["topk"][0].dist[:Q]      # first batch of the first group
     got_ids, got_dist = out_ids.cpu().numpy(), out_dist.cpu().numpy()
     if ctx.unmodelled_queries() != 0:
         raise SystemExit("bench: a query's HashMap would have treeified a bin during the run (Java order not modelled)")
