@@ -354,13 +354,13 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     // ---- bounded select: legal when the first `limit` entries do not depend on how many ids exist ----------------
     pl.lazy = 0;
     const bool cap_fixed = java_final_cap_host(c->cap0, mt) == c->cap0;       // HashMap never resizes
-    const bool legal = c->d_inv && c->d_ids_bk && c->bk_epoch == c->meta_epoch && !pl.need_cap && cap_fixed && !want_counters && limit <= 512 && pl.lds_mode;
+    const bool legal = c->d_inv && c->d_ids_bk && c->bk_epoch == c->meta_epoch && !pl.need_cap && cap_fixed && !want_counters && limit <= (for_tick ? 512 : 1024) && pl.lds_mode;
     if (legal && c->route_mode != 1 && (c->route_mode == 2 || static_cast<int64_t>(limit) * 4 <= mt)) {
         const int cap_env = c->knob_lazy_cap;   // tests: distinct ids one query may hold before it is handed back
         // size class: 512 entries (19.6 KB, 6 workgroups per CU) when limit <= 256 and the probe's scratch fits the smaller key
         // array; the tick kernel keeps the large class (its redo runs the full select over the same LDS)
         const bool small_cls = c->knob_lazy_small && !for_tick && limit <= 256 && (kLzThreads / 16) * (2 * pl.P - 1) * 12 <= 512 * 4;
-        const int kent = small_cls ? 512 : kLzEntriesMax;
+        const int kent = small_cls ? 512 : (limit <= 512 ? kLzEntriesMax : 2048);
         const size_t lds = lz_lds_bytes(kent, c->TD, pl.P);
         if (TP < 32768 && lds <= budget && (small <= lds || !for_tick)) {   // small <= lds: a handed-over query runs the full select over this LDS
             pl.lazy = 1;
@@ -1064,6 +1064,13 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     if (pl.lazy) {
         if (pl.lz_entries == 512) {
             hipLaunchKernelGGL((route_select_lazy_kernel<kLzThreads, 512>), dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
+        } else if (pl.lz_entries == 2048) {
+            auto lk = route_select_lazy_kernel<kLzThreads, 2048>;
+            if (!(c->attr_mask & 1024u)) {
+                FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                c->attr_mask |= 1024u;
+            }
+            hipLaunchKernelGGL(lk, dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
         } else {
             auto lk = route_select_lazy_kernel<kLzThreads, kLzEntriesMax>;
             if (!(c->attr_mask & 16u)) {

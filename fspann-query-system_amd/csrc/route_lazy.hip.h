@@ -23,7 +23,7 @@
 //
 // Preconditions (checked by the host, otherwise route_select_kernel runs): the HARD_CAP cannot trigger
 // (T*D*P*S < HARD_CAP), the HashMap never resizes (T*D*P*S <= 0.75 * initial capacity, so the bucket of an id does
-// not depend on how many ids were inserted), no table holds an id twice, out_kept == out_raw == NULL, limit <= 512.
+// not depend on how many ids were inserted), no table holds an id twice, out_kept == out_raw == NULL, limit <= 1024.
 // A query whose entries do not fit (degenerate hashCodes: one bucket bin holding hundreds of ids) is appended to an
 // overflow list and redone by route_select_kernel (qlist mode) — same results, just slower.
 #pragma once
@@ -33,9 +33,9 @@ namespace fspann {
 
 constexpr uint64_t kLzEmpty = ~0ull;
 constexpr int kLzThreads = 256;
-// Two size classes (template parameter kEnt = distinct ids one query may hold before it is handed over): 1024 for limit <= 512,
-// and 512 for limit <= 256 — 19.6 KB of LDS and 6 workgroups per CU instead of 33 KB and 4, so that Route workgroups and the
-// refinement scan's (37 KB, 128 registers each) fit on a CU side by side instead of taking turns.
+// Three size classes (template parameter kEnt = distinct ids one query may hold before it is handed over): 512 for limit <= 256
+// (19.6 KB of LDS, 6 workgroups per CU: the kernel's throughput follows its workgroups per CU), 1024 for
+// limit <= 512 (33 KB, 4 per CU) and 2048 for limit <= 1024 (BASELINE config #4's B; 63 KB, 2 per CU).
 constexpr int kLzEntriesMax = 1024;
 constexpr int kLzCollMax = 256;     // entries sharing (score, bucket) with another one
 constexpr int lz_ht_size(int kEnt) { return 2 * kEnt; }          // hash slots (64-bit entries): load <= 0.5
@@ -103,7 +103,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 
     constexpr int kLzHtSize = lz_ht_size(kEnt), kLzEntries = kEnt, kLzSortMax = lz_sort_max(kEnt);
     constexpr int kLzStageU = lz_stage_u(kEnt), kLzKeep = lz_keep(kEnt);
-    static_assert(kEnt == 512 || kEnt == 1024, "size classes");
+    static_assert(kEnt == 512 || kEnt == 1024 || kEnt == 2048, "size classes");
     size_t o = 0;
     uint64_t* ht = reinterpret_cast<uint64_t*>(smem + o);        o += static_cast<size_t>(kLzHtSize) * 8;
     int4* plist = reinterpret_cast<int4*>(smem + o);             o += static_cast<size_t>(TP) * 16;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 
     __shared__ int s_u, s_R, s_ncoll, s_bad, s_b, s_cnt, s_short;
     constexpr uint32_t ht_mask = kLzHtSize - 1;
-    constexpr int ht_shift = (kEnt == 1024) ? 32 - 11 : 32 - 10;
+    constexpr int ht_shift = (kEnt == 2048) ? 32 - 12 : (kEnt == 1024) ? 32 - 11 : 32 - 10;   // 32 - log2(hash slots)
     unsigned long long lt_mask = 0;
 
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
@@ -593,7 +593,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 }
 
 template <int kThreads, int kEnt>
-__global__ __launch_bounds__(kThreads, (kEnt <= 512 ? 6 : 4)) void route_select_lazy_kernel(RouteParams prm) {
+__global__ __launch_bounds__(kThreads, (kEnt <= 512 ? 6 : (kEnt <= 1024 ? 4 : 2))) void route_select_lazy_kernel(RouteParams prm) {
     extern __shared__ __align__(16) unsigned char smem[];
     route_lazy_run<kThreads, kEnt>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
 }

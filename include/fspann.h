@@ -169,7 +169,7 @@ int fspann_unmodelled_queries(fspann_ctx* ctx, int64_t* total, int reset);
 int64_t fspann_route_max_candidates(fspann_ctx* ctx, int probe_override);
 int fspann_effective_probes(fspann_ctx* ctx, int probe_override); /* PIS:880-888 */
 /* Select path of fspann_route: 0 = auto, 1 = always the full select, 2 = the bounded select whenever it is legal
- * (limit <= 512, kept/raw_seen not requested, HARD_CAP and HashMap resize out of reach).  The bounded select reads
+ * (limit <= 1024, kept/raw_seen not requested, HARD_CAP and HashMap resize out of reach).  The bounded select reads
  * only the probed partitions with the smallest Hamming distances; every mode returns the identical list.        */
 int fspann_set_route_mode(fspann_ctx* ctx, int mode);
 /* Diagnostics: which select the last route call ran and how many queries the bounded select handed back. */

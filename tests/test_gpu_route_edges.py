@@ -55,7 +55,7 @@ def check_route(pkg, sc, nq=16, probes=-1, limits=(None,), java_hash=None, impor
                 assert res["count"][i] == n
                 assert np.array_equal(res["ids"][i, :n], ids[i, :n]), (lim, i)
                 assert np.array_equal(res["score"][i, :n], score[i, :n]), (lim, i)
-            if lim and lim <= 512:
+            if lim and lim <= 1024:
                 # the bounded select (no counters requested): same first `lim` entries wherever it is legal
                 ctx.set_route_mode(2)
                 res2 = ctx.route(codes, probe_override=probes, limit=lim, counters=False)
@@ -290,3 +290,16 @@ def test_hamming_prefilter_threshold_is_order_equivalent(pkg, oracle):
         assert np.array_equal(sel, ref["sel"][:, :150])
         assert np.array_equal(rt2["ids"], rt["ids"])
         assert (rt["score"][np.arange(32), 0] <= tau).any()        # the threshold actually splits some lists
+
+
+def test_bounded_select_size_classes(pkg, oracle):
+    """limit <= 256 -> 512-entry class, <= 512 -> 1024, <= 1024 -> 2048 (BASELINE config #4's B): each against the oracle's list, with
+    levels wide enough that the class's entry budget is really used (16 tables x 5 probes x 64 ids per query)."""
+    sc = make_scene(oracle, n=60000, d=24, T=16, D=1, m=14, lam=2, B=1024, seed=77)
+    before = len(LAZY_RUNS)
+    check_route(pkg, sc, nq=24, limits=(200, 256, 257, 512, 513, 700, 1000, 1024))
+    runs = LAZY_RUNS[before:]
+    assert len(runs) == 8 and all(r["lazy"] for r in runs), runs
+    sc = make_scene(oracle, n=30000, d=16, T=12, D=2, m=12, lam=2, B=900, seed=78, clustered=True)
+    sc["params"]["clustered"] = True
+    check_route(pkg, sc, nq=16, probes=10, limits=(900, 1024))
