@@ -724,6 +724,49 @@ def main():
         recall = float(rec_h.mean())
         ratio = float(np.nanmean(rat_h)) if np.isfinite(rat_h).any() else None
 
+    # ---------------- recall / ratio as the candidate budget grows (untimed; README.md:299-303 quotes B = 22 000 for 0.88 on SIFT1M) --
+    # B beyond T*D*probes*blockSize cannot be reached with the default 5 probes: the sweep raises the probe override with B.
+    recall_sweep = None
+    if rank == 0 and extras and recall is not None:
+        recall_sweep = []
+        S_blk = 64
+        for Bs in (256, 6000, 22000):
+            pov = -1 if Bs <= 256 else min(64, -(-Bs // (TD * S_blk)) + 2)          # enough probed partitions for Bs distinct ids
+            try:
+                cfg_s = pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=lam, dim=d, seed=13, refinement_limit=Bs,
+                                               max_global_candidates=max(20000, Bs))
+                with pkg.FspannContext(cfg_s, local_rank) as cs:
+                    cs.set_gfunctions(*ctx.get_gfunctions())
+                    cs.set_id_meta(n)
+                    for td in range(TD):
+                        cs.set_index(td, **ctx.get_index(td))
+                    cs.finalize()
+                    cs.store_attach_dev(n, ctx.L.fspann_store_dev_ptr(ctx.handle, None), F32)
+                    s_ids = torch.full((Q, Bs), -1, dtype=torch.int32, device=dev)
+                    s_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
+                    o_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
+                    o_dst = torch.zeros((Q, k), dtype=torch.float64, device=dev)
+                    o_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
+                    o_sc = torch.zeros(Q, dtype=torch.int32, device=dev)
+                    o_bad = torch.zeros(Q, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()
+                    t_s = time.perf_counter()
+                    cs.search_store_dev(Q, q_all[0].data_ptr(), F32, pov, Bs, k, o_ids.data_ptr(), o_dst.data_ptr(), o_cnt.data_ptr(), o_sc.data_ptr(),
+                                        s_ids.data_ptr(), s_cnt.data_ptr(), o_bad.data_ptr())
+                    cs.sync()
+                    ms_s = (time.perf_counter() - t_s) * 1e3
+                    cs.eval_metrics_dev(n, base_ptr, Q, q_all[0].data_ptr(), d, k, o_ids.data_ptr(), k, o_cnt.data_ptr(), gt_d.data_ptr(), k,
+                                        rec_d.data_ptr(), rat_d.data_ptr())
+                    cs.sync()
+                    rat_s = rat_d.cpu().numpy()[:nv]
+                    recall_sweep.append(dict(B=Bs, probes=int(cs.effective_probes(pov)), recall_at_10=round(float(rec_d.cpu().numpy()[:nv].mean()), 5),
+                                             distance_ratio_at_10=round(float(np.nanmean(rat_s)), 5) if np.isfinite(rat_s).any() else None,
+                                             scored_mean=round(float(o_sc.float().mean().item()), 1), ms_first_call=round(ms_s, 2),
+                                             unmodelled=int(cs.unmodelled_queries())))
+                    del s_ids
+            except Exception as e:      # the sweep is a report, never a reason to lose the bench line
+                recall_sweep.append(dict(B=Bs, error=str(e)[:200]))
+
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) --------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -812,6 +855,7 @@ def main():
                                       "gather": "rows packed into [Q][B][d] by a gather kernel inside the step, then scanned"}[mode]},
             "recall_at_10": recall,
             "distance_ratio_at_10": ratio,
+            "recall_sweep": recall_sweep,
             "setup": {"build_index_s": round(setup_build_s, 3),
                       "note": "fspann_build_index of the whole base set: H2D of the vectors, coding (MFMA pre-filter + exact re-check), "
                               "radix sorts + partition cut of every table on the GPU, treeify replay of the staging map on the host"},
