@@ -198,15 +198,8 @@ def main():
     ctx.store_set(X)                                        # plaintext rows: source of the dense blocks / the store variant
     ctxs = [ctx]
     nctx = max(1, args.contexts) if args.pipeline == "concurrent" else 1
-    for _ in range(nctx - 1):                               # further contexts (own HIP streams) over the same frozen index
-        c2 = pkg.FspannContext(cfg, local_rank)
-        c2.set_gfunctions(*ctx.get_gfunctions())
-        c2.set_id_meta(n)
-        for td in range(TD):
-            c2.set_index(td, **ctx.get_index(td))
-        c2.finalize()
-        c2.store_attach_dev(n, ctx.L.fspann_store_dev_ptr(ctx.handle, None), F32)     # same rows, no second copy
-        ctxs.append(c2)
+    for _ in range(nctx - 1):                               # further contexts (own HIP streams) reading the SAME frozen index in HBM
+        ctxs.append(ctx.clone())
     if rank == 0:
         log(f"[bench] setup {time.time() - t0:.1f}s: n={n} d={d} T*D={TD} bits={m * lam} B={B} Q/GPU={Q} k={k} data={args.data}")
 

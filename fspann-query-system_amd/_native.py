@@ -103,6 +103,7 @@ _vp, _i, _i32, _i64, _sz = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_size_t
 _SIGS = {
     "fspann_ctx_create": (_i, [_i, C.POINTER(Cfg), C.POINTER(_vp)]),
     "fspann_ctx_destroy": (None, [_vp]),
+    "fspann_ctx_clone": (_i, [_vp, C.POINTER(_vp)]),
     "fspann_last_error": (C.c_char_p, []),
     "fspann_version": (C.c_char_p, []),
     "fspann_ctx_stream": (_vp, [_vp]),

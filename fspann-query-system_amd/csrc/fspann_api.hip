@@ -468,6 +468,14 @@ template <class F> int guarded(F&& f) noexcept {
         if (_e != hipSuccess) return fail(FSPANN_E_DEVICE, "hipSetDevice(%d): %s", (c)->device, hipGetErrorString(_e)); \
     } while (0)
 
+// State shared through fspann_ctx_clone is read-only: a clone cannot change it, its owner cannot while clones are alive.
+#define CHECK_UNSHARED(c)                                                                                               \
+    do {                                                                                                                \
+        if ((c)->share_parent) return fail(FSPANN_E_STATE, "a clone reads its parent's index: it cannot be changed here"); \
+        if ((c)->share_children > 0) return fail(FSPANN_E_STATE, "the index is shared with %d clone(s): destroy them first", (c)->share_children); \
+    } while (0)
+
+
 }  // namespace
 
 extern "C" {
@@ -556,6 +564,17 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->share_children > 0 && !c->zombie) {      // clones still read this context's arrays: keep them until the last clone goes
+        c->zombie = true;
+        return;
+    }
+    fspann_ctx* parent = c->share_parent;
+    if (parent) {                                   // a clone owns none of the shared arrays
+        c->d_alphaT = nullptr; c->d_r = nullptr; c->d_omega = nullptr; c->d_alphaT32 = nullptr;
+        c->d_tables = nullptr; c->d_recs = nullptr; c->d_ids = nullptr; c->d_dir = nullptr; c->d_inv = nullptr; c->d_ids_bk = nullptr;
+        c->d_java_hash = nullptr; c->d_deleted_bits = nullptr;
+        if (!c->store_owned) c->d_store = nullptr;
+    }
     free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_dev(c->ws_fix.p);
     free_devt(c->d_tables); free_devt(c->d_recs); free_devt(c->d_ids); free_devt(c->d_dir);
     free_devt(c->d_java_hash); free_devt(c->d_deleted_bits); free_devt(c->d_unmodelled);
@@ -566,6 +585,36 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    if (parent && --parent->share_children == 0 && parent->zombie) fspann_ctx_destroy(parent);
+}
+
+// A context that shares src's frozen state (include/fspann.h).
+int fspann_ctx_clone(fspann_ctx* src, fspann_ctx** out) {
+    CHECK_CTX(src);
+    if (!out) return fail(FSPANN_E_NULL, "out is null");
+    if (!src->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
+    if (src->zombie) return fail(FSPANN_E_STATE, "context was destroyed");
+    fspann_ctx* root = src->share_parent ? src->share_parent : src;      // clones of clones share the same owner
+    fspann_ctx* c = nullptr;
+    int rc = fspann_ctx_create(src->device, &src->cfg, &c);
+    if (rc) return rc;
+    c->have_g = root->have_g; c->alpha_norm_max = root->alpha_norm_max; c->encode_mode = src->encode_mode;
+    c->h_alpha = root->h_alpha; c->h_r = root->h_r; c->h_omega = root->h_omega;
+    c->d_alphaT = root->d_alphaT; c->d_r = root->d_r; c->d_omega = root->d_omega; c->d_alphaT32 = root->d_alphaT32;
+    c->h_tables = root->h_tables;
+    c->h_table_set.assign(c->TD, 1);
+    c->d_tables = root->d_tables; c->d_recs = root->d_recs; c->rec_words = root->rec_words; c->d_dir = root->d_dir; c->dir_bits = root->dir_bits;
+    c->d_ids = root->d_ids; c->d_inv = root->d_inv; c->d_ids_bk = root->d_ids_bk;
+    c->meta_epoch = root->meta_epoch; c->bk_epoch = root->bk_epoch; c->route_mode = src->route_mode;
+    c->total_parts = root->total_parts; c->total_ids = root->total_ids;
+    c->n_ids = root->n_ids; c->d_java_hash = root->d_java_hash; c->d_deleted_bits = root->d_deleted_bits; c->decimal_ids = root->decimal_ids;
+    c->d_store = root->d_store; c->store_owned = false; c->store_dtype = root->store_dtype; c->store_n = root->store_n;
+    c->dev_index_dirty = false;
+    c->frozen = true;
+    c->share_parent = root;
+    root->share_children++;
+    *out = c;
+    return FSPANN_OK;
 }
 
 void* fspann_ctx_stream(fspann_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
@@ -578,6 +627,7 @@ int fspann_sync(fspann_ctx* c) {
 
 int fspann_set_gfunctions(fspann_ctx* c, const double* alpha, const double* r, const double* omega) {
     CHECK_CTX(c);
+    CHECK_UNSHARED(c);
     if (!alpha || !r || !omega) return fail(FSPANN_E_NULL, "alpha/r/omega is null");
     const int P = c->P_total, d = c->cfg.dim;
     for (int p = 0; p < P; p++)
@@ -618,6 +668,7 @@ int fspann_set_gfunctions(fspann_ctx* c, const double* alpha, const double* r, c
 // y = dot(v, alpha_j) with the exact fp64 kernel, from which omega_j = max(1e-6, max-min)/2.5.
 int fspann_registry_initialize(fspann_ctx* c, const double* sample, int64_t ns, int64_t base_seed) {
     CHECK_CTX(c);
+    CHECK_UNSHARED(c);
     if (!sample) return fail(FSPANN_E_NULL, "sample");
     if (ns <= 0) return fail(FSPANN_E_ARG, "Sample vectors cannot be empty");
     const int TD = c->TD, m = c->cfg.m, d = c->cfg.dim, P = c->P_total, D = c->cfg.divisions;
@@ -705,6 +756,7 @@ int fspann_get_gfunctions(fspann_ctx* c, double* alpha, double* r, double* omega
 int fspann_set_index(fspann_ctx* c, int td, int64_t n_parts, const int64_t* min_key, const int64_t* max_key,
                      const uint64_t* rep, const int64_t* id_off, const int32_t* ids) {
     CHECK_CTX(c);
+    CHECK_UNSHARED(c);
     if (td < 0 || td >= c->TD) return fail(FSPANN_E_ARG, "td %d out of range [0,%d)", td, c->TD);
     if (n_parts < 0) return fail(FSPANN_E_ARG, "n_parts < 0");
     if (n_parts > 0 && (!min_key || !max_key || !rep || !id_off || !ids)) return fail(FSPANN_E_NULL, "index array is null");
@@ -732,6 +784,7 @@ int fspann_set_index(fspann_ctx* c, int td, int64_t n_parts, const int64_t* min_
 
 int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, const uint8_t* deleted) {
     CHECK_CTX(c);
+    CHECK_UNSHARED(c);
     if (n_ids <= 0 || n_ids >= (1LL << 31)) return fail(FSPANN_E_ARG, "n_ids out of range");
     c->frozen = false;           // Route stays off until the next successful fspann_finalize re-validates every table
     return guarded([&]() -> int {
@@ -761,6 +814,8 @@ int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, c
 
 int fspann_finalize(fspann_ctx* c) {
     CHECK_CTX(c);
+    if (c->share_parent) return FSPANN_OK;      // a clone is frozen with its parent's state
+    if (c->share_children > 0) return fail(FSPANN_E_STATE, "the index is shared with %d clone(s): destroy them first", c->share_children);
     if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized");
     if (c->n_ids <= 0) return fail(FSPANN_E_STATE, "id metadata not set (fspann_set_id_meta)");
     if (c->dev_index_dirty) {
@@ -786,6 +841,7 @@ extern "C" {
 
 int fspann_index_save(fspann_ctx* c, const char* path) {
     CHECK_CTX(c);
+    if (c->share_parent) c = c->share_parent;   // the host mirror of a shared index lives in its owner
     if (!path) return fail(FSPANN_E_NULL, "path is null");
     if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
     FILE* f = std::fopen(path, "wb");
@@ -820,6 +876,7 @@ int fspann_index_save(fspann_ctx* c, const char* path) {
 
 int fspann_index_load(fspann_ctx* c, const char* path) {
     CHECK_CTX(c);
+    CHECK_UNSHARED(c);
     if (!path) return fail(FSPANN_E_NULL, "path is null");
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(FSPANN_E_ARG, "cannot open %s", path);
@@ -874,6 +931,7 @@ int fspann_index_load(fspann_ctx* c, const char* path) {
 
 int fspann_index_dims(fspann_ctx* c, int td, int64_t* n_parts, int64_t* n_ids) {
     CHECK_CTX(c);
+    if (c->share_parent) c = c->share_parent;   // the host mirror of a shared index lives in its owner
     if (td < 0 || td >= c->TD) return fail(FSPANN_E_ARG, "td out of range");
     if (!c->h_table_set[td]) return fail(FSPANN_E_STATE, "table %d not set", td);
     if (n_parts) *n_parts = static_cast<int64_t>(c->h_min[td].size());
@@ -884,6 +942,7 @@ int fspann_index_dims(fspann_ctx* c, int td, int64_t* n_parts, int64_t* n_ids) {
 int fspann_get_index(fspann_ctx* c, int td, int64_t* min_key, int64_t* max_key, uint64_t* rep, int64_t* id_off,
                      int32_t* ids) {
     CHECK_CTX(c);
+    if (c->share_parent) c = c->share_parent;   // the host mirror of a shared index lives in its owner
     if (td < 0 || td >= c->TD) return fail(FSPANN_E_ARG, "td out of range");
     if (!c->h_table_set[td]) return fail(FSPANN_E_STATE, "table %d not set", td);
     std::copy(c->h_min[td].begin(), c->h_min[td].end(), min_key);
@@ -1188,6 +1247,7 @@ int fspann_refine(fspann_ctx* c, int64_t nq, const void* q, const void* cand, in
 // ---- plaintext store (test / bench harness) ----------------------------------------------
 int fspann_store_set(fspann_ctx* c, int64_t n, const void* vectors, int dtype) {
     CHECK_CTX(c);
+    if (c->share_children > 0) return fail(FSPANN_E_STATE, "the store is shared with %d clone(s): destroy them first", c->share_children);
     if (!vectors) return fail(FSPANN_E_NULL, "vectors is null");
     if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
     if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
@@ -1208,6 +1268,7 @@ int fspann_store_set(fspann_ctx* c, int64_t n, const void* vectors, int dtype) {
 // memory alive and unchanged while the context refers to it (until the next store_set / store_attach / ctx_destroy).
 int fspann_store_attach_dev(fspann_ctx* c, int64_t n, const void* vectors_dev, int dtype) {
     CHECK_CTX(c);
+    if (c->share_children > 0) return fail(FSPANN_E_STATE, "the store is shared with %d clone(s): destroy them first", c->share_children);
     if (!vectors_dev) return fail(FSPANN_E_NULL, "vectors is null");
     if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
     if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
@@ -2245,6 +2306,7 @@ int fspann_d2h(fspann_ctx* c, void* dst, const void* src_dev, size_t bytes) {
 // here (valid while no bin treeifies; DESIGN.md "Java order key").
 int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype, const int32_t* order) {
     CHECK_CTX(c);
+    CHECK_UNSHARED(c);
     if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized");
     if (!vectors) return fail(FSPANN_E_NULL, "vector cannot be null");
     if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");

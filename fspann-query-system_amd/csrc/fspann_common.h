@@ -163,6 +163,12 @@ struct fspann_ctx {
     unsigned fix_valid = 0;
     int fix_next = 0;
     fspann::DevBuf ws_io[8];   // staging for the host-pointer entry points
+
+    // fspann_ctx_clone: a clone reads its parent's GFunctions, frozen index, id metadata and store in place (no second copy in
+    // HBM, and ONE working set in the caches however many contexts serve it); it owns its stream and work areas.
+    fspann_ctx* share_parent = nullptr;  // non-null: the index arrays above belong to that context
+    int share_children = 0;              // clones alive; the shared state may not change while > 0
+    bool zombie = false;                 // destroyed by its owner while clones were alive: freed with the last clone
 };
 
 namespace fspann {

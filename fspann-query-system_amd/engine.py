@@ -69,6 +69,17 @@ class FspannContext:
         self.device = device
 
     # -- lifecycle -----------------------------------------------------------
+    def clone(self) -> "FspannContext":
+        """A context on the same device that reads THIS context's GFunctions, frozen index, id metadata and store in place
+        (fspann_ctx_clone) and owns its stream and work areas: one index in HBM served from several streams."""
+        other = FspannContext.__new__(FspannContext)
+        other.cfg, other.L = self.cfg, self.L
+        h = C.c_void_p()
+        N.check(self.L.fspann_ctx_clone(self._h, C.byref(h)))
+        other._h = h
+        other.TD, other.bits, other.W, other.hard_cap, other.device = self.TD, self.bits, self.W, self.hard_cap, self.device
+        return other
+
     def close(self):
         if getattr(self, "_h", None):
             self.L.fspann_ctx_destroy(self._h)

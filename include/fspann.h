@@ -70,6 +70,13 @@ typedef struct fspann_cfg {
 /* ---- lifecycle ----------------------------------------------------------------- */
 int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out);
 void fspann_ctx_destroy(fspann_ctx* ctx);
+/* A second context on the same device that READS src's GFunctions, frozen index, id metadata and store in place — no
+ * second copy in HBM, one working set in the caches — and owns its HIP stream and work areas: the way to serve one index from
+ * several threads / streams (a context is not re-entrant; the reference shares one PartitionedIndexService between its
+ * query threads the same way, PIS:68-73).  src must be finalized.  While clones are alive the shared state is read-only
+ * (the mutating entry points return FSPANN_E_STATE on the owner and on the clones); destroying the owner first is allowed,
+ * its arrays are released with the last clone.                                                                            */
+int fspann_ctx_clone(fspann_ctx* src, fspann_ctx** out);
 const char* fspann_last_error(void);
 const char* fspann_version(void);
 /* hipStream_t of the context, as void* (for hipEvent timing / torch.cuda.ExternalStream). */

@@ -119,3 +119,42 @@ def test_corrupt_index_files_fail_cleanly(pkg, oracle, tmp_path):
     with _ctx(pkg, sc) as ctx:
         with pytest.raises(pkg.FspannArgumentError):
             ctx.load_index(os.path.join(str(tmp_path), "does_not_exist.fsx"))
+
+
+def test_clone_shares_the_index_and_keeps_it_read_only(pkg, oracle):
+    """fspann_ctx_clone: same results from the clone, shared state read-only on both sides while the clone lives, the owner may go first."""
+    from conftest import make_scene
+    sc = make_scene(oracle, n=9000, d=16, T=5, D=1, m=10, lam=2, B=128, seed=31)     # B >= 10 K: QSI's adaptive retry stays off
+    p = sc["params"]
+    cfg = pkg.PaperRuntimeConfig(tables=p["T"], divisions=p["D"], m=p["m"], lambda_=p["lam"], dim=p["d"], refinement_limit=p["B"],
+                                 max_global_candidates=p["hard_cap"])
+    Q = sc["rng"].standard_normal((40, p["d"])).astype(np.float32)
+    ctx = pkg.FspannContext(cfg, 0)
+    ctx.set_gfunctions(sc["alpha"], sc["r"], sc["omega"])
+    ctx.set_id_meta(p["n"])
+    with pytest.raises(pkg.FspannStateError, match="not finalized"):
+        ctx.clone()
+    ctx.build_index(sc["X"])
+    ctx.store_set(sc["X"])
+    ref = sc["oracle"].search(Q.astype(np.float64), 10)
+    cl = ctx.clone()
+    cl2 = cl.clone()                                           # a clone of a clone shares the same owner
+    for c_ in (ctx, cl, cl2):
+        codes = c_.encode(Q)
+        rt = c_.route(codes, limit=p["B"], counters=False)
+        rs = c_.refine_store(Q, rt["ids"][:, :p["B"]], rt["count"], 10)
+        assert np.array_equal(rt["count"], ref["sel_count"])
+        assert np.array_equal(rs["ids"], ref["ids"]) and np.array_equal(rs["dist"], ref["dist"])
+    assert all(np.array_equal(cl.get_index(0)[k_], v_) for k_, v_ in ctx.get_index(0).items())
+    for c_ in (ctx, cl):                                       # read-only on both sides
+        with pytest.raises(pkg.FspannStateError, match="clone"):
+            c_.set_id_meta(p["n"])
+        with pytest.raises(pkg.FspannStateError, match="clone"):
+            c_.build_index(sc["X"])
+    ctx.close()                                                # the owner goes first: its arrays live on for the clones
+    codes = cl.encode(Q)
+    rt = cl.route(codes, limit=p["B"], counters=False)
+    rs = cl2.refine_store(Q, rt["ids"][:, :p["B"]], rt["count"], 10)
+    assert np.array_equal(rs["ids"], ref["ids"]) and np.array_equal(rs["dist"], ref["dist"])
+    cl.close()
+    cl2.close()

@@ -24,6 +24,9 @@ full = torch.full((Q,), B, dtype=torch.int32, device=dev)
 def mk(nctx):
     ctxs = [ctx0]
     for _ in range(nctx - 1):
+        if os.environ.get("SHARE", "1") == "1":          # clones read context 0's index in place (SHARE=0: a copy per context)
+            ctxs.append(ctx0.clone())
+            continue
         c2 = pkg.FspannContext(cfg, 0)
         c2.set_gfunctions(*ctx0.get_gfunctions()); c2.set_id_meta(n)
         for td in range(T):
