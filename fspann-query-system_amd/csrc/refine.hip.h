@@ -111,7 +111,7 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
     __shared__ uint64_t s_wcut[kRefRows / 64];
     __shared__ int s_wbase[kRefRows / 64], s_wsurvn[kRefRows / 64];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- stable rank by (distance bits, candidate position) -------------------------------------
     // Scratch lives in each wave's OWN (now dead) tile rows, so the per-wave steps need no workgroup barrier:
     //   wkeys[64]  the wave's keys           wsurv[64]  the wave's survivors (keys <= the chunk-wide cut)
@@ -383,7 +383,7 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     const int32_t* __restrict__ cand_ids = a.cand_ids;
     TC* tile = reinterpret_cast<TC*>(smem);                                              // [kRefRows][PITCH]
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // a scalar: what derives from it is scalar work
     const int ntile = (d + DC - 1) / DC;
     const int64_t nunits = nq * nchunks;
     const int slot_row = wave * 64 + lane / VPR;          // + i * (64 / VPR): row of this lane's i-th 16-byte slot

@@ -74,9 +74,8 @@ __global__ __launch_bounds__(kTickThreads, 4) void tick_kernel(const TickHead h,
         route_lazy_run<kLzThreads>(route, smem, idx, h.n_route, idx);
 #endif
     } else if (role == kTickRefine) {
-        // One workgroup per query (refine_scan_block).  Measured alternatives inside this kernel: the streaming scan
-        // (refine_stream_run, a quarter of the workgroups) is 1.4-1.7x slower here than in its own kernel — the shared
-        // kernel is compiled for the register budget of its hungriest role — and made the launch slower overall.
+        // One workgroup per query.  (A quarter of the workgroups streaming several queries each was 1.4-1.7x slower here than in
+        // its own kernel while the scan still needed 152 registers — this kernel has 128 — and made the launch slower overall.)
         const int64_t qi = idx;                                   // nchunks == 1 (host): one workgroup per query
         int cnt = ref.cand_count[qi];
 #ifndef TICK_NO_FIX
@@ -92,7 +91,10 @@ __global__ __launch_bounds__(kTickThreads, 4) void tick_kernel(const TickHead h,
             cnt = __hip_atomic_load(const_cast<int32_t*>(ref.cand_count) + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // not through a stale cache line
         }
 #endif
-        refine_scan_block<float, float, 32, true, GATHER>(ref, smem, idx, cnt);
+        // dense blocks: the streaming scan's per-unit code (buffer loads, two tiles in flight, nt policy) with one unit per
+        // workgroup; the store gather keeps the scan block
+        if constexpr (!GATHER) refine_stream_run<float, float, 32, false>(ref, smem, qi, static_cast<int64_t>(h.n_refine), h.nq_refine, true);
+        else refine_scan_block<float, float, 32, true, GATHER>(ref, smem, idx, cnt);
     } else {
 #ifndef TICK_NO_ENC
         encode_exact_block<float, kTickEncQB>(enc, idx % h.enc_gx, idx / h.enc_gx, reinterpret_cast<int32_t*>(smem));
