@@ -129,12 +129,13 @@ def main():
     ap.add_argument("--route-counters", action="store_true", help="also produce lastCandKept / rawSeen (forces the full select)")
     ap.add_argument("--host-threads", type=int, default=16, help="host threads of the end-to-end pipeline's AES-GCM pool (0: every core this process may use)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts (each with its own HIP stream) per GPU for --pipeline concurrent")
-    ap.add_argument("--pipeline", default="concurrent", choices=["concurrent", "serial", "tick"],
-                    help="concurrent (value): --contexts independent contexts per GPU take the batches in turn, each running encode -> "
+    ap.add_argument("--pipeline", default="front", choices=["concurrent", "front", "serial", "tick"],
+                    help="concurrent: --contexts independent contexts per GPU take the batches in turn, each running encode -> "
                          "Route -> Refine of ITS batch as three kernels on its own HIP stream; the hardware queues overlap the "
                          "latency-bound Route of one batch with the bandwidth-bound Refine of another.  serial: one context, one stream "
                          "(latency of a single batch, nothing overlaps).  tick: one stream, three batches in flight, encode(t+2) + "
-                         "Route(t+1) + Refine(t) as ONE kernel (fspann_tick_dev)")
+                         "Route(t+1) + Refine(t) as ONE kernel (fspann_tick_dev).  front (value): as concurrent, but a context runs the encode "
+                         "of its NEXT batch and the Route of this one as ONE launch (fspann_tick_dev without a Refine part), then the scan")
     args = ap.parse_args()
 
     # Only the final JSON line may reach stdout: libraries (RCCL prints a version banner) write to fd 1 too.
@@ -197,7 +198,7 @@ def main():
     setup_build_s = time.time() - t_b
     ctx.store_set(X)                                        # plaintext rows: source of the dense blocks / the store variant
     ctxs = [ctx]
-    nctx = max(1, args.contexts) if args.pipeline == "concurrent" else 1
+    nctx = max(1, args.contexts) if args.pipeline in ("concurrent", "front") else 1
     for _ in range(nctx - 1):                               # further contexts (own HIP streams) reading the SAME frozen index in HBM
         ctxs.append(ctx.clone())
     if rank == 0:
@@ -226,7 +227,9 @@ def main():
                     slot=[dict(codes=torch.zeros((Q, TD, W), dtype=torch.int64, device=dev), bad=torch.zeros(Q, dtype=torch.int32, device=dev),
                                sel_ids=torch.full((Q, B), -1, dtype=torch.int32, device=dev), sel_cnt=torch.zeros(Q, dtype=torch.int32, device=dev),
                                hov=torch.zeros(max(1, ctx.route_handover_bytes(Q, probe_passes[-1])), dtype=torch.uint8, device=dev))
-                          for _ in range(3)], tick_no=0)
+                          for _ in range(3)], tick_no=0,
+                    # front pipeline: the codes of this context's current and next batch
+                    fcodes=[torch.zeros((Q, TD, W), dtype=torch.int64, device=dev) for _ in range(2)], front_no=0)
 
     bufs = [mkbufs() for _ in ctxs]
     streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
@@ -282,6 +285,7 @@ def main():
 
     torch.cuda.synchronize()
     step_no = [0]
+    use_front = [False]   # set by timed() for the region it times (the untimed passes use the plain three-launch step)
     active = [1]          # contexts the steps alternate between
     overlapped = [None]   # (dispatches, mean ms) of sampled refinement scans that ran next to other contexts' kernels
 
@@ -294,6 +298,19 @@ def main():
         qp = q_all[bi].data_ptr()
         cx, stream, b = ctxs[si], streams[si], bufs[si]
         par, ids_p, dist_p, last = out_slot(b)
+        if use_front[0] and events is None and batch is None and mode == "dense":
+            # ONE launch for encode(next batch of this context) + Route(this batch), then the scan of this batch's block
+            j = b["front_no"]
+            b["front_no"] += 1
+            fb, nb_ = j % NB, (j + 1) % NB
+            cx.tick_dev(encode=dict(nq=Q, q=q_all[nb_].data_ptr(), codes=b["fcodes"][(j + 1) & 1].data_ptr(), bad=b["bad"].data_ptr()),
+                        route=dict(nq=Q, codes=b["fcodes"][j & 1].data_ptr(), limit=B, probe_override=probe_passes[-1], ids=b["sel_ids"].data_ptr(),
+                                   count=b["sel_cnt"].data_ptr()),
+                        refine=None)
+            cx.refine_dev(Q, q_all[fb].data_ptr(), F32, cand_all[fb].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k, ids_p, dist_p,
+                          b["out_cnt"].data_ptr(), b["scored"].data_ptr())
+            merge(b, par, stream, si, last)
+            return
         if mode == "store" and events is None and not args.route_counters:
             # the whole step in ONE library call (encode -> bounded select -> refine from the store, stream order)
             for pov in probe_passes:
@@ -408,7 +425,7 @@ def main():
         if use_dist:
             dist.barrier()
 
-    def timed(mode, steps, warmup, nact=1, with_events=False):
+    def timed(mode, steps, warmup, nact=1, with_events=False, front=False):
         """`steps` steps over `nact` contexts taking the batches in turn: (elapsed seconds, max over ranks; (dispatches, ms) of the
         refinement-scan launches that carried kernel-attached events; their spacing).  With one context every `every`-th scan
         dispatch carries the events.  With several, kernels of different contexts overlap, so for a SOLO reading every
@@ -418,6 +435,11 @@ def main():
         for b_ in bufs:
             b_["nsteps"] = 0
         step_no[0] = 0
+        use_front[0] = front and mode == "dense" and len(probe_passes) == 1 and not args.route_counters
+        if use_front[0]:
+            for c_, b_ in zip(ctxs[:nact], bufs[:nact]):       # fill the pipeline (untimed): the codes of every context's first batch
+                b_["front_no"] = 0
+                c_.encode_dev(Q, q_all[0].data_ptr(), F32, b_["fcodes"][0].data_ptr(), 0, b_["bad"].data_ptr())
         for _ in range(warmup):
             step(mode)
         barrier()
@@ -459,6 +481,7 @@ def main():
                 on = sum(x for x, _ in ov)
                 overlapped[0] = (on, sum(t for _, t in ov) / max(1, on))
         active[0] = 1
+        use_front[0] = False
         return el, rt, every
 
     # ---------------- the timed region ------------------------------------------------------------------------------------
@@ -468,7 +491,7 @@ def main():
         elapsed, rt, TIMED_EVERY = timed_tick(mode, args.steps, args.warmup, with_events=True)
         tick_fused = ctx.last_tick_fused()
     else:
-        elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, nact=nctx, with_events=True)
+        elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, nact=nctx, with_events=True, front=args.pipeline == "front")
         tick_fused = False
     overlapped_main = overlapped[0]
     ref_launches = sum(x for x, _ in rt)
@@ -495,6 +518,10 @@ def main():
             variants["serial"] = dict(value=round(Q * args.steps / el_s, 1), unit="queries/s", ms_per_step=round(el_s * 1000.0 / args.steps, 4),
                                       note="ONE context, one stream: the three stages of one batch as three kernels one after the other (encode, Route, "
                                            "Refine); nothing overlaps")
+        if args.pipeline == "front" and nctx > 1:
+            el_c, _, _ = timed(mode, args.steps, max(2, args.warmup), nact=nctx)
+            variants["concurrent"] = dict(value=round(Q * args.steps / el_c, 1), unit="queries/s", ms_per_step=round(el_c * 1000.0 / args.steps, 4),
+                                          note="the same contexts with encode, Route and Refine of a batch as three separate kernels per step")
         if mode in ("dense", "store") and len(probe_passes) == 1 and not args.route_counters and not use_tick:
             el_t, _, _ = timed_tick(mode, args.steps, max(2, args.warmup))
             variants["tick"] = dict(value=round(Q * args.steps / el_t, 1), unit="queries/s", ms_per_step=round(el_t * 1000.0 / args.steps, 4),
@@ -839,6 +866,9 @@ def main():
                        "parallelism": f"query-sharded x{world}, index replicated", "merge": gather_path, "streams_per_gpu": nctx,
                        "pipeline": ("tick: 3 batches in flight, one launch per step = encode(t+2) + Route(t+1) + Refine(t) as one kernel (tick_kernel, "
                                     "fused=%s); every step does one full-batch encode, Route and Refine" % tick_fused) if use_tick
+                       else ("front: %d contexts per GPU take the batches in turn, each running encode(its next batch) + Route(this batch) as ONE "
+                             "launch (front_kernel: encode workgroups beside the bounded select's) and then the scan of this batch, on its own HIP "
+                             "stream" % nctx) if args.pipeline == "front"
                        else ("concurrent: %d contexts per GPU take the batches in turn, each running encode -> Route -> Refine of its batch as three "
                              "kernels on its own HIP stream (hardware queues overlap Route of one batch with Refine of another)" % nctx) if nctx > 1
                        else "serial: encode, Route, Refine of one batch as three kernels on one stream",

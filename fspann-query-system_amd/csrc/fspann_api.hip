@@ -1413,9 +1413,11 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
     RoutePlan plR{}, plX{};
     RouteParams pR{}, pX{};
     bool fusedR = false, fusedX = false;
+    // encode + Route without a Refine part: the front kernel (tick.hip.h), which may use the bounded select's small classes
+    const bool front = E && R && !F && t->route_limit <= 512 && t->enc_dtype == FSPANN_F32 && c->knob_tick_fuse != 0;
     if (R) {
         if ((rc = prepare_route(c, t->nq_route, t->route_codes_dev, t->route_probe_override, t->route_limit, t->route_limit, t->route_ids_dev,
-                                nullptr, t->route_count_dev, nullptr, nullptr, &plR, &pR, &fusedR, true))) return rc;
+                                nullptr, t->route_count_dev, nullptr, nullptr, &plR, &pR, &fusedR, !front))) return rc;
         if (t->route_handover_dev) handover_ptrs(c, t->route_handover_dev, t->nq_route, plR.P, &pR.probe_g, &pR.nprobe_g);
     }
     const bool fix = F && t->ref_handover_dev != nullptr;
@@ -1550,7 +1552,19 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
         FSP_HIP(hipGetLastError());
         return FSPANN_OK;
     };
-    if ((rc = gather ? launch(tick_kernel<true>, 128u) : launch(tick_kernel<false>, 256u))) return rc;
+    if (front && (plR.lz_entries == 512 || plR.lz_entries == kLzEntriesMax)) {
+        if (plR.lz_entries == 512) {
+            hipLaunchKernelGGL(front_kernel<512>, dim3(static_cast<unsigned>(total)), dim3(kTickThreads), lds, c->stream, p, eaT, routeT);
+        } else {
+            auto fk = front_kernel<kLzEntriesMax>;
+            if (!(c->attr_mask & 2048u)) {
+                FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                c->attr_mask |= 2048u;
+            }
+            hipLaunchKernelGGL(fk, dim3(static_cast<unsigned>(total)), dim3(kTickThreads), lds, c->stream, p, eaT, routeT);
+        }
+        FSP_HIP(hipGetLastError());
+    } else if ((rc = gather ? launch(tick_kernel<true>, 128u) : launch(tick_kernel<false>, 256u))) return rc;
     if (R && !t->route_handover_dev) {
         // no buffer travels with the batch: queries the bounded select handed over are finished now (normally none)
         RouteParams q2 = pR;
