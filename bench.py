@@ -400,7 +400,7 @@ def main():
         for _ in range(warmup):
             tick(mode)
         barrier()
-        every = max(2, steps // 8)
+        every = max(2, steps // max(1, min(8, steps // 40)))
         if with_events:
             ctxs[0].refine_timing_begin(steps, 1)          # only the unfused steps launch a refinement scan of their own
         t_s = time.perf_counter()
@@ -444,7 +444,7 @@ def main():
         for _ in range(warmup):
             step(mode)
         barrier()
-        every = max(2, steps // 8)                      # about eight timed dispatches whatever --steps is
+        every = max(2, steps // max(1, min(8, steps // 40)))   # up to eight solo readings, at most one per 40 steps (a drain costs ~2 steps)
         solo_n, solo_ms = 0, 0.0
         if with_events and nact == 1:
             ctxs[0].refine_timing_begin(steps, every)
