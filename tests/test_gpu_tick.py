@@ -234,3 +234,35 @@ def test_route_after_a_tick_with_handed_over_queries(pkg, oracle, monkeypatch):
             ref = o.search(Qs[b].astype(np.float64), K)
             assert np.array_equal(got["count"], ref["sel_count"]), b
             assert np.array_equal(np.where(np.arange(B)[None] < got["count"][:, None], got["ids"][:, :B], -1), ref["sel"][:, :B]), b
+
+
+@pytest.mark.parametrize("B", [200, 256, 400])
+def test_front_launch_equals_encode_and_route(pkg, oracle, B):
+    """fspann_tick_dev without a Refine part = front_kernel (encode of one batch + bounded select of another in ONE launch, small size
+    classes allowed): the codes and the routed lists are exactly what fspann_encode / the oracle's Route give, with and without a
+    hand-over buffer, also when queries overflow the class (second launch finishes them)."""
+    import torch
+    sc = make_scene(oracle, n=50000, d=32, T=16, D=1, m=14, lam=2, B=B, seed=41)
+    o, p = sc["oracle"], sc["params"]
+    TD, W = p["T"], 1
+    dev = torch.device("cuda", 0)
+    Qa = sc["rng"].standard_normal((300, 32)).astype(np.float32)
+    Qb = sc["rng"].standard_normal((300, 32)).astype(np.float32)
+    with _ctx(pkg, sc) as ctx:
+        ctx.build_index(sc["X"])
+        codes_b_ref = o.encode(Qb.astype(np.float64))
+        ref_b = o.search(Qb.astype(np.float64), K)
+        qa = torch.from_numpy(Qa).to(dev)
+        codes_a = torch.zeros((300, TD, W), dtype=torch.int64, device=dev)
+        codes_b = torch.from_numpy(codes_b_ref.view(np.int64)).to(dev)
+        bad = torch.zeros(300, dtype=torch.int32, device=dev)
+        sel = torch.full((300, B), -1, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(300, dtype=torch.int32, device=dev)
+        ctx.tick_dev(encode=dict(nq=300, q=qa.data_ptr(), codes=codes_a.data_ptr(), bad=bad.data_ptr()),
+                     route=dict(nq=300, codes=codes_b.data_ptr(), limit=B, ids=sel.data_ptr(), count=cnt.data_ptr()), refine=None)
+        ctx.sync()
+        assert ctx.last_tick_fused() and ctx.last_route_info()["lazy"]
+        assert np.array_equal(codes_a.cpu().numpy().view(np.uint64), o.encode(Qa.astype(np.float64))) and not bad.cpu().numpy().any()
+        c_h, s_h = cnt.cpu().numpy(), sel.cpu().numpy()
+        assert np.array_equal(c_h, ref_b["sel_count"])
+        assert np.array_equal(np.where(np.arange(B)[None] < c_h[:, None], s_h, -1), ref_b["sel"][:, :B])
