@@ -230,7 +230,10 @@ def main():
                                hov=torch.zeros(max(1, ctx.route_handover_bytes(Q, probe_passes[-1])), dtype=torch.uint8, device=dev))
                           for _ in range(3)], tick_no=0,
                     # front pipeline: the codes of this context's current and next batch
-                    fcodes=[torch.zeros((Q, TD, W), dtype=torch.int64, device=dev) for _ in range(2)], front_no=0)
+                    fcodes=[torch.zeros((Q, TD, W), dtype=torch.int64, device=dev) for _ in range(2)], front_no=0, last_front=None,
+                    # ... and the hand-over buffer its Route writes and its scan consumes (a query the bounded select cannot hold is
+                    # finished by the scan's own workgroups: no hand-back launch)
+                    fhov=torch.zeros(max(1, ctx.route_handover_bytes(Q, probe_passes[-1])), dtype=torch.uint8, device=dev))
 
     bufs = [mkbufs() for _ in ctxs]
     streams = [torch.cuda.ExternalStream(c_.stream, device=dev) for c_ in ctxs]
@@ -294,22 +297,26 @@ def main():
         """One pass of the hot path over one batch.  mode: dense | store | gather.  events: 5 torch events recorded around
         the stages (untimed breakdown passes only)."""
         si = step_no[0] % active[0] if force_ctx is None else force_ctx
-        bi = (step_no[0] // active[0]) % NB if batch is None else batch
+        bi = step_no[0] % NB if batch is None else batch      # consecutive steps (whatever their context) take DIFFERENT batches
         step_no[0] += 1
         qp = q_all[bi].data_ptr()
         cx, stream, b = ctxs[si], streams[si], bufs[si]
         par, ids_p, dist_p, last = out_slot(b)
         if use_front[0] and events is None and batch is None and mode == "dense":
             # ONE launch for encode(next batch of this context) + Route(this batch), then the scan of this batch's block
+            # context si's j-th step takes batch j * contexts + si: the contexts work on DIFFERENT batches at any moment
             j = b["front_no"]
             b["front_no"] += 1
-            fb, nb_ = j % NB, (j + 1) % NB
+            fb, nb_ = (j * active[0] + si) % NB, ((j + 1) * active[0] + si) % NB
             cx.tick_dev(encode=dict(nq=Q, q=q_all[nb_].data_ptr(), codes=b["fcodes"][(j + 1) & 1].data_ptr(), bad=b["bad"].data_ptr()),
                         route=dict(nq=Q, codes=b["fcodes"][j & 1].data_ptr(), limit=B, probe_override=probe_passes[-1], ids=b["sel_ids"].data_ptr(),
-                                   count=b["sel_cnt"].data_ptr()),
+                                   count=b["sel_cnt"].data_ptr(), handover=b["fhov"].data_ptr()),
                         refine=None)
-            cx.refine_dev(Q, q_all[fb].data_ptr(), F32, cand_all[fb].data_ptr(), F32, B, b["sel_ids"].data_ptr(), b["sel_cnt"].data_ptr(), k, ids_p, dist_p,
-                          b["out_cnt"].data_ptr(), b["scored"].data_ptr())
+            cx.tick_dev(refine=dict(nq=Q, q=q_all[fb].data_ptr(), B=B, ids=b["sel_ids"].data_ptr(), count=b["sel_cnt"].data_ptr(), k=k,
+                                    cand=cand_all[fb].data_ptr(), codes=b["fcodes"][j & 1].data_ptr(), handover=b["fhov"].data_ptr(),
+                                    probe_override=probe_passes[-1], out_ids=ids_p, out_dist=dist_p, out_count=b["out_cnt"].data_ptr(),
+                                    scored=b["scored"].data_ptr()))
+            b["last_front"] = (fb, par, (b["nsteps"] - 1) % MG)
             merge(b, par, stream, si, last)
             return
         if mode == "store" and events is None and not args.route_counters:
@@ -438,9 +445,9 @@ def main():
         step_no[0] = 0
         use_front[0] = front and mode == "dense" and len(probe_passes) == 1 and not args.route_counters
         if use_front[0]:
-            for c_, b_ in zip(ctxs[:nact], bufs[:nact]):       # fill the pipeline (untimed): the codes of every context's first batch
+            for si_, (c_, b_) in enumerate(zip(ctxs[:nact], bufs[:nact])):   # fill the pipeline (untimed): the codes of every context's first batch
                 b_["front_no"] = 0
-                c_.encode_dev(Q, q_all[0].data_ptr(), F32, b_["fcodes"][0].data_ptr(), 0, b_["bad"].data_ptr())
+                c_.encode_dev(Q, q_all[si_ % NB].data_ptr(), F32, b_["fcodes"][0].data_ptr(), 0, b_["bad"].data_ptr())
         for _ in range(warmup):
             step(mode)
         barrier()
@@ -503,6 +510,41 @@ def main():
         elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, nact=nctx, with_events=True, front=args.pipeline == "front")
         tick_fused = False
     overlapped_main = overlapped[0]
+    # ---------------- what was timed is what is checked: the LAST step each context ran inside the timed region (front_kernel +
+    # the scan that finishes PENDING queries, on the clones' own streams) against the plain three-launch path on context 0 for the
+    # same batch here, and against the CPU oracle in the cpu_baseline leg ------------------------------------------------------
+    timed_check = None
+    if args.pipeline == "front" and not use_tick and bufs[0]["last_front"] is not None:
+        snaps = []
+        for si_, b_ in enumerate(bufs[:nctx]):
+            if b_["last_front"] is None:
+                continue
+            fb_, par_, slot_ = b_["last_front"]
+            tk_ = b_["topk"][par_]
+            snaps.append(dict(ctx=si_, batch=fb_, ids=tk_.ids[slot_ * Q:(slot_ + 1) * Q].cpu().numpy().copy(),
+                              dist=tk_.dist[slot_ * Q:(slot_ + 1) * Q].cpu().numpy().copy(), count=b_["out_cnt"].cpu().numpy().copy(),
+                              sel=b_["sel_ids"].cpu().numpy().copy(), sel_cnt=b_["sel_cnt"].cpu().numpy().copy()))
+        ok_all = True
+        for sn in snaps:
+            for b_ in bufs:
+                b_["nsteps"] = 0
+            step_no[0] = 0
+            step(mode, batch=sn["batch"], force_ctx=0)         # plain path: encode, Route (+ hand-back launch), scan on context 0
+            barrier()
+            r_ids, r_dist = bufs[0]["topk"][0].ids[:Q].cpu().numpy(), bufs[0]["topk"][0].dist[:Q].cpu().numpy()
+            r_sel, r_cnt = bufs[0]["sel_ids"].cpu().numpy(), bufs[0]["sel_cnt"].cpu().numpy()
+            live = np.arange(B)[None] < r_cnt[:, None]
+            same = (np.array_equal(sn["ids"], r_ids) and np.array_equal(sn["dist"], r_dist) and np.array_equal(sn["sel_cnt"], r_cnt)
+                    and np.array_equal(np.where(live, sn["sel"], -1), np.where(live, r_sel, -1)))
+            sn["same_as_plain"] = bool(same)
+            ok_all = ok_all and same
+        if not ok_all:
+            raise SystemExit("bench: the timed front pipeline's results differ from the plain path: %s"
+                             % [(sn["ctx"], sn["batch"], sn["same_as_plain"]) for sn in snaps])
+        timed_check = dict(contexts=len(snaps), batches=[sn["batch"] for sn in snaps], same_as_plain_path=True, same_as_oracle=None,
+                           note="outputs of the last step every context ran INSIDE the timed region (front_kernel + scan on its own stream), "
+                                "compared with the three-launch path on context 0 and, in the cpu_baseline leg, with the CPU oracle")
+        timed_snaps = snaps
     ref_launches = sum(x for x, _ in rt)
     ref_ms = sum(t for _, t in rt) / max(1, ref_launches)          # kernel-attached HIP events, on the context's stream
     ms_per_step = elapsed * 1000.0 / args.steps
@@ -830,6 +872,18 @@ def main():
             raise SystemExit("bench: a HashMap bin treeified in the oracle at this workload: the checker has no pinned order")
         if not (same and index_same):
             raise SystemExit(f"bench: GPU results differ from the CPU oracle (index_same={index_same}, results_same={same})")
+        if timed_check is not None:      # the timed launches themselves, every context, all queries
+            try:
+                nthr_o = len(os.sched_getaffinity(0))
+            except AttributeError:
+                nthr_o = os.cpu_count() or 1
+            for sn in timed_snaps:
+                ro = o.search(Qall[sn["batch"]].astype(np.float64), k, threads=nthr_o)
+                okq = (np.array_equal(ro["ids"], sn["ids"]) and np.array_equal(ro["dist"], sn["dist"]) and np.array_equal(ro["sel_count"], sn["sel_cnt"])
+                       and np.array_equal(ro["sel"][:, :B], np.where(np.arange(B)[None] < sn["sel_cnt"][:, None], sn["sel"], -1)))
+                if not okq or o.unmodelled:
+                    raise SystemExit(f"bench: timed front step of context {sn['ctx']} (batch {sn['batch']}) differs from the CPU oracle")
+            timed_check["same_as_oracle"] = True
         cpu = dict(value=round(done / cpu_s, 1), unit="queries/s", cores=1, kind="port",
                    sample=f"{ns} queries x {reps} passes of the same batch (encode + Route + Refine on plaintext, "
                           f"no AES/RocksDB), C++ oracle single thread; host has {os.cpu_count()} logical cores",
@@ -854,6 +908,20 @@ def main():
             cpu["all_cores"] = dict(value=round(done2 / (time.perf_counter() - t2), 1), unit="queries/s", cores=nthr,
                                     note="the same port, OpenMP over queries on every core this process may use")
 
+    if use_dist and comms is not None:
+        # merged result = every rank's top-k in rank order.  EVERY rank checks EVERY slice: the buffer the path's own collective
+        # filled against an independent torch.distributed all-gather of the same local buffers, then all ranks agree.
+        gat, loc = bufs[0]["gathered"][0], bufs[0]["topk"][0]
+        ref_raw = torch.zeros_like(gat.raw)
+        torch.cuda.synchronize()
+        dist.all_gather_into_tensor(ref_raw, loc.raw)
+        torch.cuda.synchronize()
+        g_ids, g_dist = gat.split()
+        own = torch.equal(g_ids[rank * Q * MG: rank * Q * MG + Q], out_ids) and torch.equal(g_dist[rank * Q * MG: rank * Q * MG + Q], out_dist)
+        okf = torch.tensor([1 if (own and torch.equal(ref_raw, gat.raw)) else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) != 1:
+            raise SystemExit(f"bench: rank {rank}: the gathered top-k differs from an independent all-gather of the ranks' buffers")
     if rank == 0:
         out = {
             "metric": ("queries/sec @ recall@10, SIFT-1M-shaped synthetic data d=128 B=256" if args.data in ("gaussian", "clustered")
@@ -875,8 +943,9 @@ def main():
                        "parallelism": f"query-sharded x{world}, index replicated", "merge": gather_path, "streams_per_gpu": nctx,
                        "pipeline": ("tick: 3 batches in flight, one launch per step = encode(t+2) + Route(t+1) + Refine(t) as one kernel (tick_kernel, "
                                     "fused=%s); every step does one full-batch encode, Route and Refine" % tick_fused) if use_tick
-                       else ("front: %d contexts per GPU take the batches in turn, each running encode(its next batch) + Route(this batch) as ONE "
-                             "launch (front_kernel: encode workgroups beside the bounded select's) and then the scan of this batch, on its own HIP "
+                       else ("front: %d contexts per GPU take the batches in turn (consecutive steps = different batches), each running encode(its next "
+                             "batch) + Route(this batch) as ONE launch (front_kernel: encode workgroups beside the bounded select's) and then the scan "
+                             "of this batch (whose workgroups finish queries the bounded select handed over: no hand-back launch), on its own HIP "
                              "stream" % nctx) if args.pipeline == "front"
                        else ("concurrent: %d contexts per GPU take the batches in turn, each running encode -> Route -> Refine of its batch as three "
                              "kernels on its own HIP stream (hardware queues overlap Route of one batch with Refine of another)" % nctx) if nctx > 1
@@ -899,16 +968,13 @@ def main():
             "route_stage": route_info,
             "variants": variants or None,
             "end_to_end": end_to_end,
+            "timed_check": timed_check,
             "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if use_dist and comms is not None and rank == 0:
-        # merged result = every rank's top-k in rank order; rank 0's own slice must be intact
-        g_ids, g_dist = bufs[0]["gathered"][0].split()
-        assert torch.equal(g_ids[:Q], out_ids) and torch.equal(g_dist[:Q], out_dist)
     for cm in (comms or []):
         cm.close()
     for c_ in ctxs[::-1]:

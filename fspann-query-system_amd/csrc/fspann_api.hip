@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <thread>
+#include <type_traits>
 #include <mutex>
 #include <new>
 #include <numeric>
@@ -416,12 +417,30 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
         // of the next two tiles in flight across unit boundaries (refine_stream_run)
         const int64_t units = nq * nchunks;
         const unsigned sgrid = static_cast<unsigned>(std::min<int64_t>(units, static_cast<int64_t>(c->num_cus) * stream_wgs));
-        auto kern = refine_stream_kernel<TC, TQ, DC, GATHER>;
-        if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {
-            hipExtLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, c->rt_events[c->rt_used], c->rt_events[c->rt_used + 1], 0, ra, nq);
-            c->rt_used += 2;
-        } else {
-            hipLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, ra, nq);
+        const bool timed = c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size();
+        hipEvent_t ev0 = timed ? c->rt_events[c->rt_used] : nullptr, ev1 = timed ? c->rt_events[c->rt_used + 1] : nullptr;
+        if (timed) c->rt_used += 2;
+        bool fixed = false;
+        if constexpr (std::is_same<TC, float>::value && std::is_same<TQ, float>::value && DC == 32) {
+            if (c->refine_fix_dev && nchunks == 1) {
+                // the batch's Route ran with a hand-over buffer: the scan's workgroups finish its PENDING queries first (tick.hip.h)
+                auto fk = refine_stream_fix_kernel<GATHER>;
+                const size_t flds = std::max(lds, c->refine_fix_lds);
+                const unsigned abit = GATHER ? 4096u : 8192u;
+                if (!(c->attr_mask & abit)) {
+                    FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                    c->attr_mask |= abit;
+                }
+                if (timed) hipExtLaunchKernelGGL(fk, dim3(sgrid), dim3(kRefRows), flds, c->stream, ev0, ev1, 0, ra, nq, static_cast<const RouteParams*>(c->refine_fix_dev));
+                else hipLaunchKernelGGL(fk, dim3(sgrid), dim3(kRefRows), flds, c->stream, ra, nq, static_cast<const RouteParams*>(c->refine_fix_dev));
+                fixed = true;
+                c->refine_fix_used = true;
+            }
+        }
+        if (!fixed) {
+            auto kern = refine_stream_kernel<TC, TQ, DC, GATHER>;
+            if (timed) hipExtLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, ev0, ev1, 0, ra, nq);
+            else hipLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, ra, nq);
         }
         streamed = true;
     }
@@ -1460,7 +1479,67 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
     fuse = fuse && lds + 1024 <= static_cast<size_t>(c->lds_limit);
     c->last_tick_fused = fuse ? 1 : 0;
 
+    // the redo's parameters live in device memory (tick.hip.h): a small cache of recently used parameter blocks, so a serving
+    // loop that cycles through a few buffer sets uploads each block once
+    auto upload_fix = [&](const RouteParams& fixT, const RouteParams** out) -> int {
+        if (!c->d_fixparams) {
+            FSP_HIP(hipMalloc(&c->d_fixparams, sizeof(RouteParams) * fspann_ctx::kFixSlots));
+            c->h_fixparams.assign(sizeof(RouteParams) * fspann_ctx::kFixSlots, 0);
+            c->fix_valid = 0;
+        }
+        int slot = -1;
+        for (int i = 0; i < fspann_ctx::kFixSlots; i++)
+            if (((c->fix_valid >> i) & 1u) && std::memcmp(c->h_fixparams.data() + sizeof(RouteParams) * i, &fixT, sizeof(RouteParams)) == 0) { slot = i; break; }
+        if (slot < 0) {
+            slot = c->fix_next;
+            c->fix_next = (c->fix_next + 1) % fspann_ctx::kFixSlots;
+            std::memcpy(c->h_fixparams.data() + sizeof(RouteParams) * slot, &fixT, sizeof(RouteParams));
+            // stream-ordered: ticks already enqueued that read this slot run before the copy
+            FSP_HIP(hipMemcpyAsync(static_cast<char*>(c->d_fixparams) + sizeof(RouteParams) * slot, &fixT, sizeof(RouteParams), hipMemcpyHostToDevice, c->stream));
+            c->fix_valid |= 1u << slot;
+        }
+        *out = reinterpret_cast<const RouteParams*>(static_cast<char*>(c->d_fixparams) + sizeof(RouteParams) * slot);
+        return FSPANN_OK;
+    };
+
+    if (F && !E && !R) {
+        // A tick with only a Refine part is the stand-alone scan.  With the batch's hand-over buffer the scan's own workgroups
+        // finish the PENDING queries first (refine_stream_fix_kernel): Route and Refine as separate launches, no hand-back launch.
+        const bool stream_ok = t->ref_q_dtype == FSPANN_F32 && rows_dtype == FSPANN_F32 && nchunks == 1 && (d % 4 == 0) &&
+                               ((reinterpret_cast<uintptr_t>(rows) & 15) == 0) && c->knob_refine_stream != 0 && c->knob_tick_fuse != 0;
+        const RouteParams* fdev = nullptr;
+        if (fix && stream_ok) {
+            pX.dbg = nullptr;
+            if ((rc = upload_fix(pX, &fdev))) return rc;
+        } else if (fix) {
+            auto fk = tick_fix_kernel;
+            if (!(c->attr_mask & 64u)) {
+                FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                c->attr_mask |= 64u;
+            }
+            hipLaunchKernelGGL(fk, dim3(static_cast<unsigned>(t->nq_refine)), dim3(kTickThreads), plX.small_bytes, c->stream, pX);
+            FSP_HIP(hipGetLastError());
+        }
+        c->refine_fix_dev = fdev;
+        c->refine_fix_lds = fdev ? plX.small_bytes : 0;
+        c->refine_fix_used = false;
+        rc = gather ? fspann_refine_store_dev(c, t->nq_refine, t->ref_q_dev, t->ref_q_dtype, t->ref_B, t->ref_ids_dev, t->ref_count_dev, t->k,
+                                              t->out_ids_dev, t->out_dist_dev, t->out_count_dev, t->scored_dev)
+                    : fspann_refine_dev(c, t->nq_refine, t->ref_q_dev, t->ref_q_dtype, t->ref_cand_dev, t->ref_cand_dtype, t->ref_B, t->ref_ids_dev,
+                                        t->ref_count_dev, t->k, t->out_ids_dev, t->out_dist_dev, t->out_count_dev, t->scored_dev);
+        const bool used = c->refine_fix_used;
+        c->refine_fix_dev = nullptr;
+        if (rc) return rc;
+        if (fdev && !used) return fail(FSPANN_E_STATE, "tick: the scan did not take the streaming kernel that finishes PENDING queries");
+        c->last_tick_fused = (c->knob_tick_fuse != 0 && nchunks == 1 && (!fix || fdev)) ? 1 : 0;
+        return FSPANN_OK;
+    }
+
     if (!fuse) {   // stand-alone kernels in stream order: same results
+        // prepare_route above took the overflow counters' turn for a bounded select this call will not launch itself: the
+        // stand-alone fspann_route_dev below takes its own.  Hand the turn back, or consecutive fall-back ticks would all
+        // count into the counter nobody zeroes (stale overflow lists, then writes past the nq-sized list).
+        if (R && plR.lazy) c->ovf_flip ^= 1;
         if (fix) {
             auto fk = tick_fix_kernel;
             if (!(c->attr_mask & 64u)) {
@@ -1514,28 +1593,8 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
         p.has_fix = fix ? 1 : 0;
         if (fix) fixT = pX;
     }
-    // the redo's parameters live in device memory (tick.hip.h): a small cache of recently used parameter blocks, so a serving
-    // loop that cycles through a few buffer sets uploads each block once
     const RouteParams* fix_dev = nullptr;
-    if (fix) {
-        if (!c->d_fixparams) {
-            FSP_HIP(hipMalloc(&c->d_fixparams, sizeof(RouteParams) * fspann_ctx::kFixSlots));
-            c->h_fixparams.assign(sizeof(RouteParams) * fspann_ctx::kFixSlots, 0);
-            c->fix_valid = 0;
-        }
-        int slot = -1;
-        for (int i = 0; i < fspann_ctx::kFixSlots; i++)
-            if (((c->fix_valid >> i) & 1u) && std::memcmp(c->h_fixparams.data() + sizeof(RouteParams) * i, &fixT, sizeof(RouteParams)) == 0) { slot = i; break; }
-        if (slot < 0) {
-            slot = c->fix_next;
-            c->fix_next = (c->fix_next + 1) % fspann_ctx::kFixSlots;
-            std::memcpy(c->h_fixparams.data() + sizeof(RouteParams) * slot, &fixT, sizeof(RouteParams));
-            // stream-ordered: ticks already enqueued that read this slot run before the copy
-            FSP_HIP(hipMemcpyAsync(static_cast<char*>(c->d_fixparams) + sizeof(RouteParams) * slot, &fixT, sizeof(RouteParams), hipMemcpyHostToDevice, c->stream));
-            c->fix_valid |= 1u << slot;
-        }
-        fix_dev = reinterpret_cast<const RouteParams*>(static_cast<char*>(c->d_fixparams) + sizeof(RouteParams) * slot);
-    }
+    if (fix) { if ((rc = upload_fix(fixT, &fix_dev))) return rc; }
     // long jobs first: a share of the Route workgroups heads the grid, the rest is spread evenly between the others
     p.route_front = F ? static_cast<int>(static_cast<int64_t>(p.n_route) * c->knob_tick_front / 100) : p.n_route;
     p.dbg = c->dbg_route;           // debug builds: the tick's own per-workgroup stamps (the roles' phase stamps stay off)

@@ -163,6 +163,11 @@ struct fspann_ctx {
     unsigned fix_valid = 0;
     int fix_next = 0;
     fspann::DevBuf ws_io[8];   // staging for the host-pointer entry points
+    // transient, set by fspann_tick_dev around a refine-only tick: device-resident RouteParams of the batch's hand-over buffer
+    // (the streaming scan then finishes PENDING queries itself), the LDS its full select needs, and whether a launch took it
+    const void* refine_fix_dev = nullptr;
+    size_t refine_fix_lds = 0;
+    bool refine_fix_used = false;
 
     // fspann_ctx_clone: a clone reads its parent's GFunctions, frozen index, id metadata and store in place (no second copy in
     // HBM, and ONE working set in the caches however many contexts serve it); it owns its stream and work areas.

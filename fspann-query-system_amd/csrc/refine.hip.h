@@ -366,9 +366,15 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
 // is refine_topk_emit.  VEC layout only (d % (16 / sizeof(TC)) == 0, 16-byte aligned rows): the host falls back otherwise.
 // counts_fresh: read cand_count with a device-scope atomic load (tick_kernel: the count of a PENDING query was rewritten
 // by this very workgroup a moment ago; a plain load could hit a stale scalar / L1 line).
-template <typename TC, typename TQ, int DC, bool GATHER>
+// `fix` (tick.hip.h: refine_stream_fix_kernel): called for a query whose Route the bounded select handed over (count = PENDING) and
+// finished here by the full select before its rows are scored; RefineNoFix = nothing to finish.
+struct RefineNoFix {
+    static constexpr bool enabled = false;
+    __device__ __forceinline__ void operator()(int64_t) const {}
+};
+template <typename TC, typename TQ, int DC, bool GATHER, class FixFn = RefineNoFix>
 __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, unsigned char* smem, const int64_t wg, const int64_t nwg,
-                                                  const int64_t nq, const bool counts_fresh) {
+                                                  const int64_t nq, const bool counts_fresh, const FixFn fix = FixFn()) {
     using V = typename VecOf<TC>::type;
     constexpr int VN = VecOf<TC>::N;
     constexpr int PITCH = DC + VN;
@@ -472,6 +478,24 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     FSP_STREAM_ISSUE(regA);
     FSP_STREAM_ISSUE(regB);
     RS_STAMP(1);
+    if constexpr (FixFn::enabled) {
+        // The first two tiles are under way; now look at the counts of this workgroup's queries (one 256-row chunk per query
+        // here: unit == query).  PENDING = handed over by the bounded select: finish its Route with the full select first —
+        // rare, so the stream simply starts again afterwards (the tiles requested above are dropped: nothing of them is live
+        // across the full select, which needs the registers).
+        bool any = false;
+        for (int64_t u = wg; u < nunits; u += nwg) any = any || (a.cand_count[u] == -2 /* kRoutePending */);
+        if (any) {
+            for (int64_t u = wg; u < nunits; u += nwg)
+                if (a.cand_count[u] == -2) fix(u);
+            iu = wg; it = 0;
+            ibase = unit_base(iu);
+            load_sources(iu);
+            if constexpr (!GATHER) irsrc = unit_rsrc();
+            FSP_STREAM_ISSUE(regA);
+            FSP_STREAM_ISSUE(regB);
+        }
+    }
 
     // ---- consume side ------------------------------------------------------------------------------------------------
     for (int64_t u = wg; u < nunits; u += nwg) {

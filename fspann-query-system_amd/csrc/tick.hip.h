@@ -118,6 +118,30 @@ __global__ __launch_bounds__(kTickThreads, (kEnt <= 512 ? 6 : 4)) void front_ker
     else route_lazy_run<kLzThreads, kEnt>(route, smem, b - h.n_enc, h.n_route, b - h.n_enc);
 }
 
+// The stand-alone streaming scan (refine_stream_kernel) for a batch whose Route ran with a hand-over buffer: every workgroup
+// finishes the Route of the PENDING queries among ITS units with the full select (normally none: one count load per unit,
+// looked at while the first two tiles are already under way), then streams.  One 256-row chunk per query only (host: nchunks == 1), so a query's F_q is read by the workgroup that
+// completed it.  This is what removes the hand-back launch from a serving loop that runs Route and Refine as separate launches.
+struct RefineRouteFix {
+    static constexpr bool enabled = true;
+    const RouteParams* fix_dev;
+    unsigned char* smem;
+    __device__ __forceinline__ void operator()(const int64_t qi) const {
+        const RouteParams fix = *fix_dev;                           // read in the rare path only (see tick_kernel)
+        const int TP = fix.TD * fix.P;
+        route_select_query<false, kRefRows>(fix, smem, static_cast<int>(blockIdx.x), fix.probe_g + qi * TP, fix.nprobe_g + qi * fix.TD, qi);
+        __threadfence();
+        __syncthreads();                                            // F_q and its count are in global memory, LDS is free again
+    }
+};
+template <bool GATHER>
+__global__ __launch_bounds__(kRefRows, (GATHER ? 2 : 4)) void refine_stream_fix_kernel(const RefineArgs<float, float> a, const int64_t nq,
+                                                                                       const RouteParams* __restrict__ fix_dev) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    refine_stream_run<float, float, 32, GATHER, RefineRouteFix>(a, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), nq, true,
+                                                                RefineRouteFix{fix_dev, smem});
+}
+
 // The same redo as its own launch (fspann_tick_dev when the three roles cannot share one kernel): a workgroup per query,
 // all but the PENDING ones leave at once.
 __global__ __launch_bounds__(kTickThreads, 4) void tick_fix_kernel(RouteParams fix) {

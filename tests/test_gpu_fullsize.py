@@ -5,6 +5,8 @@ built INDEPENDENTLY by the oracle (PIS.insert coding + GreedyPartitioner.build r
 (`fspann_build_index`), all 16 tables are compared, then every one of the 1 024 queries goes through
   * `fspann_search_store_dev` (the call bench.py times: encode -> bounded select -> refine from the resident store), and
   * the staged path with the FULL select (counters), dense candidate block, `fspann_refine`,
+  * the launch sequence of bench.py's default pipeline: front_kernel (encode + bounded select, hand-over buffer) + the scan that
+    finishes handed-over queries, on the owner and two clones running side by side, six batches of 1 024 queries,
 against `oracle.search` (PIS:372-434,592-715; QSI:101-352): routed ids, counts, lastCandKept / rawSeen, top-k ids and fp64
 distances — all bit-exact.  config #3 (1 M x 960, B = 512) the same on a query subset; config #4 (10 M x 768, 32 x 64
 bits, B = 1024) is too large for the oracle inside a test budget: there the size-independent properties are checked
@@ -48,7 +50,76 @@ def _search_store(pkg, ctx, Q, B, probes=-1):
                 sel=sel.cpu().numpy(), sel_count=selc.cpu().numpy(), bad=bad.cpu().numpy())
 
 
-def _full_parity(pkg, oracle, n, d, T, m, B, nq, seed, all_tables=True):
+def _front_pipeline_parity(pkg, ctx, o, X, rng, d, T, m, B, nq):
+    """The launch sequence bench.py's headline times (`--pipeline front`), at the headline's own size: three contexts — the owner and
+    two fspann_ctx_clone()s on their own streams — take six batches in turn; a context's step = ONE launch for encode(its next
+    batch) + Route(this batch) (front_kernel, hand-over buffer) and then the scan over the resident [Q][B][d] block, whose workgroups
+    finish queries the bounded select handed over.  Every query of every batch against oracle.search."""
+    import torch
+    dev = torch.device("cuda", 0)
+    F32 = pkg._native.F32
+    NCTX, ROUNDS = 3, 2
+    NBT = NCTX * ROUNDS
+    TD, W = T, (m * 2 + 63) // 64
+    Qb = rng.standard_normal((NBT, nq, d), dtype=np.float32)
+    refs = [o.search(Qb[b].astype(np.float64), K, threads=max(1, len(os.sched_getaffinity(0)))) for b in range(NBT)]
+    assert not o.unmodelled
+    qd = torch.from_numpy(Qb).to(dev)
+    # the host's load + decrypt of F_q (QSI:238-271), done ahead for every batch: rows in the reference's F_q order
+    cand = torch.empty((NBT, nq, B, d), dtype=torch.float32, device=dev)
+    for b in range(NBT):
+        cand[b].copy_(torch.from_numpy(X[np.maximum(refs[b]["sel"][:, :B], 0)]))
+    ctxs = [ctx, ctx.clone(), ctx.clone()]
+    try:
+        st = []
+        for c_ in ctxs:
+            st.append(dict(fcodes=[torch.zeros((nq, TD, W), dtype=torch.int64, device=dev) for _ in range(2)],
+                           bad=torch.zeros(nq, dtype=torch.int32, device=dev),
+                           hov=torch.zeros(c_.route_handover_bytes(nq), dtype=torch.uint8, device=dev),
+                           sel=[torch.full((nq, B), -1, dtype=torch.int32, device=dev) for _ in range(ROUNDS)],
+                           cnt=[torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(ROUNDS)],
+                           oi=[torch.full((nq, K), -7, dtype=torch.int32, device=dev) for _ in range(ROUNDS)],
+                           od=[torch.zeros((nq, K), dtype=torch.float64, device=dev) for _ in range(ROUNDS)],
+                           oc=[torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(ROUNDS)],
+                           sc=[torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(ROUNDS)]))
+        torch.cuda.synchronize()
+        for si, c_ in enumerate(ctxs):                                  # fill the pipeline: the codes of every context's first batch
+            c_.encode_dev(nq, qd[si].data_ptr(), F32, st[si]["fcodes"][0].data_ptr(), 0, st[si]["bad"].data_ptr())
+        fused, lazy = [], []
+        for j in range(ROUNDS):
+            for si, c_ in enumerate(ctxs):                              # nothing synchronises between the contexts' launches
+                s_ = st[si]
+                fb, nb_ = j * NCTX + si, ((j + 1) * NCTX + si) % NBT
+                c_.tick_dev(encode=dict(nq=nq, q=qd[nb_].data_ptr(), codes=s_["fcodes"][(j + 1) & 1].data_ptr(), bad=s_["bad"].data_ptr()),
+                            route=dict(nq=nq, codes=s_["fcodes"][j & 1].data_ptr(), limit=B, ids=s_["sel"][j].data_ptr(), count=s_["cnt"][j].data_ptr(),
+                                       handover=s_["hov"].data_ptr()), refine=None)
+                fused.append(c_.last_tick_fused())
+                c_.tick_dev(refine=dict(nq=nq, q=qd[fb].data_ptr(), B=B, ids=s_["sel"][j].data_ptr(), count=s_["cnt"][j].data_ptr(), k=K,
+                                        cand=cand[fb].data_ptr(), codes=s_["fcodes"][j & 1].data_ptr(), handover=s_["hov"].data_ptr(),
+                                        out_ids=s_["oi"][j].data_ptr(), out_dist=s_["od"][j].data_ptr(), out_count=s_["oc"][j].data_ptr(),
+                                        scored=s_["sc"][j].data_ptr()))
+                fused.append(c_.last_tick_fused())
+        for c_ in ctxs:
+            c_.sync()
+            lazy.append(c_.last_route_info()["lazy"])
+            assert c_.unmodelled_queries() == 0
+        assert all(fused) and all(lazy), (fused, lazy)
+        for j in range(ROUNDS):
+            for si in range(NCTX):
+                s_, ref = st[si], refs[j * NCTX + si]
+                cnt = s_["cnt"][j].cpu().numpy()
+                assert np.array_equal(cnt, ref["sel_count"]), (si, j)
+                assert np.array_equal(np.where(np.arange(B)[None] < cnt[:, None], s_["sel"][j].cpu().numpy(), -1), ref["sel"][:, :B]), (si, j)
+                assert np.array_equal(s_["oi"][j].cpu().numpy(), ref["ids"]) and np.array_equal(s_["od"][j].cpu().numpy(), ref["dist"]), (si, j)
+                assert np.array_equal(s_["oc"][j].cpu().numpy(), ref["count"]) and np.array_equal(s_["sc"][j].cpu().numpy(), ref["metrics"][:, 2]), (si, j)
+                assert not s_["bad"].cpu().numpy().any()
+    finally:
+        for c_ in ctxs[1:]:
+            c_.close()
+    del cand, qd
+
+
+def _full_parity(pkg, oracle, n, d, T, m, B, nq, seed, all_tables=True, front=False):
     lam, D = 2, 1
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((n, d), dtype=np.float32)
@@ -101,6 +172,8 @@ def _full_parity(pkg, oracle, n, d, T, m, B, nq, seed, all_tables=True):
             cand = X[np.maximum(sel[s:e], 0)]
             out = ctx.refine(Q[s:e], cand, sel[s:e], rt["count"][s:e], K)
             assert np.array_equal(out["ids"], ref["ids"][s:e]) and np.array_equal(out["dist"], ref["dist"][s:e])
+        if front:
+            _front_pipeline_parity(pkg, ctx, o, X, rng, d, T, m, B, nq)
         # -- the whole list of a few queries (lookupCandidatesWithScores, no truncation)
         ids, score, count, raw = o.route(codes[:8])
         full = ctx.route(codes[:8])
@@ -113,7 +186,7 @@ def _full_parity(pkg, oracle, n, d, T, m, B, nq, seed, all_tables=True):
 
 def test_config2_sift1m_shape_full_size(pkg, oracle):
     """BASELINE config #2 exactly: N = 1 M x 128, T*D = 16, m = 16, lambda = 2, B = 256, Q = 1024."""
-    info = _full_parity(pkg, oracle, n=1_000_000, d=128, T=16, m=16, B=256, nq=1024, seed=1)
+    info = _full_parity(pkg, oracle, n=1_000_000, d=128, T=16, m=16, B=256, nq=1024, seed=1, front=True)
     assert info["lazy"], "fspann_search_store_dev did not take the bounded select at the headline configuration"
     assert info["overflowed"] <= 8
 

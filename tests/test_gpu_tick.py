@@ -151,6 +151,27 @@ def test_tick_finishes_handed_over_queries(pkg, oracle, handover, monkeypatch):
     assert info["lazy"]
 
 
+@pytest.mark.parametrize("how", ["B300", "fuse_off"])
+def test_tick_fallback_hands_over_on_consecutive_ticks(pkg, oracle, how, monkeypatch):
+    """Regression (overflow-counter ping-pong): on the stand-alone fall-back path the tick's own Route plan and the
+    fspann_route_dev it then calls both took the counters' turn, so consecutive fall-back ticks all counted into the counter
+    nobody zeroes — stale overflow lists, then writes past the nq-sized list.  Several consecutive ticks whose bounded select
+    hands queries over, on both ways into the fall-back (B > 256, FSPANN_TICK_FUSE=0)."""
+    monkeypatch.setenv("FSPANN_ROUTE_LAZY_CAP", "258")
+    if how == "fuse_off":
+        monkeypatch.setenv("FSPANN_TICK_FUSE", "0")
+    B = 300 if how == "B300" else 256
+    sc = make_scene(oracle, n=40000, d=16, T=10, D=1, m=12, lam=2, B=B, seed=23)
+    Qb = sc["rng"].standard_normal((6, 96, 16)).astype(np.float32)
+    with _ctx(pkg, sc) as ctx:
+        ctx.build_index(sc["X"])
+        ctx.store_set(sc["X"])
+        out = _pipeline(pkg, ctx, sc, Qb, dense=False, handover=False, expect_fused=False)
+        info = ctx.last_route_info()
+        assert info["lazy"] and 0 < info["overflowed"] <= 96, info      # this call's list only, never an accumulated one
+    _check(sc, Qb, out)
+
+
 def test_tick_flags_treeified_queries_in_the_redo(pkg, oracle):
     """Degenerate hashCodes: every query is handed over AND its HashMap would treeify a bin -> the redo flags it (count -1),
     Refine returns nothing for it, the context counts it."""
