@@ -115,6 +115,12 @@ _SIGS = {
     "fspann_set_id_meta": (_i, [_vp, _i64, _vp, _vp]),
     "fspann_finalize": (_i, [_vp]),
     "fspann_build_index": (_i, [_vp, _i64, _vp, _i, _vp]),
+    "fspann_build_begin": (_i, [_vp, _i64]),
+    "fspann_build_append": (_i, [_vp, _i64, _vp, _i]),
+    "fspann_build_finish": (_i, [_vp, _vp]),
+    "fspann_set_deleted": (_i, [_vp, _vp, _i64, _i]),
+    "fspann_route_resolve_dev": (_i, [_vp, _i64, _vp, _i, _i32, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "fspann_search_store_finish_dev": (_i, [_vp, _i64, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     "fspann_index_save": (_i, [_vp, C.c_char_p]),
     "fspann_index_load": (_i, [_vp, C.c_char_p]),
     "fspann_index_dims": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -20,6 +20,7 @@
 #include "route.hip.h"
 #include "route_lazy.hip.h"
 #include "tick.hip.h"
+#include "../host/route_replay.hpp"
 
 using namespace fspann;
 
@@ -466,6 +467,9 @@ int launch_refine_t(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int6
     return launch_refine_dc<TC, TQ, DC0, GATHER>(c, nq, q, cand, B, cand_ids, cand_count, k, out_ids, out_dist, out_count, scored);
 }
 
+int resolve_unmodelled(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit, int64_t cap, int32_t* ids_dev,
+                       int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev, int32_t* raw_dev, int64_t* resolved_out, int64_t* left_out);   // api_ext.hip.h
+
 // No C++ exception crosses the C ABI (include/fspann.h): every entry point that allocates host memory or starts
 // threads runs its body through guarded(); worker threads catch on their own and report through a flag.
 template <class F> int guarded(F&& f) noexcept {
@@ -480,18 +484,25 @@ template <class F> int guarded(F&& f) noexcept {
     }
 }
 
-#define CHECK_CTX(c)                                                      \
+#define CHECK_CTX_NOLOCK(c)                                               \
     do {                                                                  \
         if (!(c)) return fail(FSPANN_E_NULL, "ctx is null");              \
         hipError_t _e = hipSetDevice((c)->device);                        \
         if (_e != hipSuccess) return fail(FSPANN_E_DEVICE, "hipSetDevice(%d): %s", (c)->device, hipGetErrorString(_e)); \
     } while (0)
+// ... and the context's lock for the rest of the entry point (calls on one context are serialised inside the library)
+#define CHECK_CTX(c)         \
+    CHECK_CTX_NOLOCK(c);     \
+    std::lock_guard<std::recursive_mutex> _ctx_lock((c)->mu)
+
+// the deleted-id mirror of the index this context serves (its own, or its owner's when it is a clone)
+inline fspann_ctx* index_owner(fspann_ctx* c) { return c->share_parent ? c->share_parent : c; }
 
 // State shared through fspann_ctx_clone is read-only: a clone cannot change it, its owner cannot while clones are alive.
 #define CHECK_UNSHARED(c)                                                                                               \
     do {                                                                                                                \
         if ((c)->share_parent) return fail(FSPANN_E_STATE, "a clone reads its parent's index: it cannot be changed here"); \
-        if ((c)->share_children > 0) return fail(FSPANN_E_STATE, "the index is shared with %d clone(s): destroy them first", (c)->share_children); \
+        if ((c)->share_children.load() > 0) return fail(FSPANN_E_STATE, "the index is shared with %d clone(s): destroy them first", (c)->share_children.load()); \
     } while (0)
 
 
@@ -583,11 +594,16 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->share_children > 0 && !c->zombie) {      // clones still read this context's arrays: keep them until the last clone goes
-        c->zombie = true;
-        return;
-    }
     fspann_ctx* parent = c->share_parent;
+    {
+        // the family's bookkeeping (clones alive, owner gone) changes under the OWNER's lock: clones are driven — and destroyed —
+        // from different threads
+        std::unique_lock<std::recursive_mutex> fam((parent ? parent : c)->mu);
+        if (!parent && c->share_children.load() > 0 && !c->zombie) {   // clones still read this context's arrays: keep them until the last clone goes
+            c->zombie = true;
+            return;
+        }
+    }
     if (parent) {                                   // a clone owns none of the shared arrays
         c->d_alphaT = nullptr; c->d_r = nullptr; c->d_omega = nullptr; c->d_alphaT32 = nullptr;
         c->d_tables = nullptr; c->d_recs = nullptr; c->d_ids = nullptr; c->d_dir = nullptr; c->d_inv = nullptr; c->d_ids_bk = nullptr;
@@ -596,24 +612,33 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     }
     free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_dev(c->ws_fix.p);
     free_devt(c->d_tables); free_devt(c->d_recs); free_devt(c->d_ids); free_devt(c->d_dir);
-    free_devt(c->d_java_hash); free_devt(c->d_deleted_bits); free_devt(c->d_unmodelled);
+    free_devt(c->d_java_hash); free_devt(c->d_unmodelled);
+    if (uint32_t* db = c->d_deleted_bits.exchange(nullptr)) (void)hipFree(db);
     if (c->store_owned) free_dev(c->d_store);
-    free_dev(c->ws_tickfix.p); free_dev(c->d_fixparams); free_dev(c->ws_gt.p);
+    free_dev(c->ws_tickfix.p); free_dev(c->d_fixparams); free_dev(c->ws_gt.p); free_dev(c->bld_codes.p);
     free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
-    if (parent && --parent->share_children == 0 && parent->zombie) fspann_ctx_destroy(parent);
+    if (parent) {
+        bool last_of_zombie;
+        {
+            std::unique_lock<std::recursive_mutex> fam(parent->mu);
+            last_of_zombie = (--parent->share_children == 0) && parent->zombie;
+        }
+        if (last_of_zombie) fspann_ctx_destroy(parent);   // exactly one clone sees the transition to zero
+    }
 }
 
 // A context that shares src's frozen state (include/fspann.h).
 int fspann_ctx_clone(fspann_ctx* src, fspann_ctx** out) {
-    CHECK_CTX(src);
+    CHECK_CTX_NOLOCK(src);
     if (!out) return fail(FSPANN_E_NULL, "out is null");
-    if (!src->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
-    if (src->zombie) return fail(FSPANN_E_STATE, "context was destroyed");
     fspann_ctx* root = src->share_parent ? src->share_parent : src;      // clones of clones share the same owner
+    std::lock_guard<std::recursive_mutex> fam(root->mu);                 // the owner's state is read (and its clone count raised) under its lock
+    if (!src->frozen) return fail(FSPANN_E_STATE, "Index not finalized");
+    if (src->zombie || root->zombie) return fail(FSPANN_E_STATE, "context was destroyed");
     fspann_ctx* c = nullptr;
     int rc = fspann_ctx_create(src->device, &src->cfg, &c);
     if (rc) return rc;
@@ -626,7 +651,7 @@ int fspann_ctx_clone(fspann_ctx* src, fspann_ctx** out) {
     c->d_ids = root->d_ids; c->d_inv = root->d_inv; c->d_ids_bk = root->d_ids_bk;
     c->meta_epoch = root->meta_epoch; c->bk_epoch = root->bk_epoch; c->route_mode = src->route_mode;
     c->total_parts = root->total_parts; c->total_ids = root->total_ids;
-    c->n_ids = root->n_ids; c->d_java_hash = root->d_java_hash; c->d_deleted_bits = root->d_deleted_bits; c->decimal_ids = root->decimal_ids;
+    c->n_ids = root->n_ids; c->d_java_hash = root->d_java_hash; c->decimal_ids = root->decimal_ids;   // (deleted bits: read from the owner at every call)
     c->d_store = root->d_store; c->store_owned = false; c->store_dtype = root->store_dtype; c->store_n = root->store_n;
     c->dev_index_dirty = false;
     c->frozen = true;
@@ -811,17 +836,22 @@ int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, c
     c->decimal_ids = (java_hash == nullptr);
     if (java_hash) std::copy(java_hash, java_hash + n_ids, c->h_java_hash.begin());
     else for (int64_t i = 0; i < n_ids; i++) c->h_java_hash[i] = decimal_string_hash(i);
-    free_devt(c->d_java_hash); free_devt(c->d_deleted_bits);
+    free_devt(c->d_java_hash);
+    if (uint32_t* db = c->d_deleted_bits.exchange(nullptr)) (void)hipFree(db);
     FSP_HIP(hipMalloc(&c->d_java_hash, static_cast<size_t>(n_ids) * 4));
     FSP_HIP(hipMemcpy(c->d_java_hash, c->h_java_hash.data(), static_cast<size_t>(n_ids) * 4, hipMemcpyHostToDevice));
-    if (deleted) {
+    {
+        std::lock_guard<std::mutex> dl(c->deleted_mu);
+        c->h_deleted_bits.assign(static_cast<size_t>((n_ids + 31) / 32), 0u);
         bool any = false;
-        std::vector<uint32_t> bits(static_cast<size_t>((n_ids + 31) / 32), 0u);
-        for (int64_t i = 0; i < n_ids; i++)
-            if (deleted[i]) { bits[i >> 5] |= (1u << (i & 31)); any = true; }
-        if (any) {
-            FSP_HIP(hipMalloc(&c->d_deleted_bits, bits.size() * 4));
-            FSP_HIP(hipMemcpy(c->d_deleted_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+        if (deleted)
+            for (int64_t i = 0; i < n_ids; i++)
+                if (deleted[i]) { c->h_deleted_bits[i >> 5] |= (1u << (i & 31)); any = true; }
+        if (any) {      // (none deleted: the kernels skip the lookup until the first fspann_set_deleted)
+            uint32_t* db = nullptr;
+            FSP_HIP(hipMalloc(&db, c->h_deleted_bits.size() * 4));
+            if (hipMemcpy(db, c->h_deleted_bits.data(), c->h_deleted_bits.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(db); return fail(FSPANN_E_DEVICE, "hipMemcpy failed"); }
+            c->d_deleted_bits.store(db, std::memory_order_release);
         }
     }
     c->meta_epoch++;             // d_inv / d_ids_bk were built for the previous hashes: the bounded select waits for the next finalize
@@ -834,7 +864,7 @@ int fspann_set_id_meta(fspann_ctx* c, int64_t n_ids, const int32_t* java_hash, c
 int fspann_finalize(fspann_ctx* c) {
     CHECK_CTX(c);
     if (c->share_parent) return FSPANN_OK;      // a clone is frozen with its parent's state
-    if (c->share_children > 0) return fail(FSPANN_E_STATE, "the index is shared with %d clone(s): destroy them first", c->share_children);
+    if (c->share_children.load() > 0) return fail(FSPANN_E_STATE, "the index is shared with %d clone(s): destroy them first", c->share_children.load());
     if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized");
     if (c->n_ids <= 0) return fail(FSPANN_E_STATE, "id metadata not set (fspann_set_id_meta)");
     if (c->dev_index_dirty) {
@@ -876,10 +906,10 @@ int fspann_index_save(fspann_ctx* c, const char* path) {
     ok = ok && wr(f, c->h_alpha.data(), c->h_alpha.size()) && wr(f, c->h_r.data(), c->h_r.size()) && wr(f, c->h_omega.data(), c->h_omega.size());
     ok = ok && wr(f, c->h_java_hash.data(), c->h_java_hash.size());
     std::vector<uint8_t> del(static_cast<size_t>(c->n_ids), 0);
-    if (c->d_deleted_bits) {
-        std::vector<uint32_t> bits(static_cast<size_t>((c->n_ids + 31) / 32));
-        if (hipMemcpy(bits.data(), c->d_deleted_bits, bits.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
-        for (int64_t i = 0; i < c->n_ids; i++) del[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+    {
+        std::lock_guard<std::mutex> dl(c->deleted_mu);
+        if (!c->h_deleted_bits.empty())
+            for (int64_t i = 0; i < c->n_ids; i++) del[i] = (c->h_deleted_bits[i >> 5] >> (i & 31)) & 1u;
     }
     ok = ok && wr(f, del.data(), del.size());
     for (int td = 0; td < c->TD && ok; td++) {
@@ -1051,7 +1081,7 @@ int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int prob
     RouteParams p{};
     p.codes = codes_dev; p.tables = c->d_tables; p.recs = c->d_recs; p.rec_words = c->rec_words; p.ids = c->d_ids;
     p.dir = c->knob_probe_dir ? c->d_dir : nullptr; p.dir_bits = c->dir_bits;
-    p.java_hash = c->d_java_hash; p.deleted_bits = c->d_deleted_bits;
+    p.java_hash = c->d_java_hash; p.deleted_bits = index_owner(c)->d_deleted_bits.load(std::memory_order_acquire);
     p.nq = nq; p.TD = c->TD; p.W = c->W; p.P = pl.P; p.S = pl.S; p.S_shift = pl.S_shift;
     p.hard_cap = c->hard_cap; p.cap0 = c->cap0; p.limit = limit; p.need_cap = pl.need_cap; p.nbins = pl.nbins;
     p.seq_bits = 1; while ((1 << p.seq_bits) < pl.max_tuples) p.seq_bits++;
@@ -1190,17 +1220,24 @@ int fspann_route(fspann_ctx* c, int64_t nq, const uint64_t* codes, int probe_ove
                           static_cast<int32_t*>(c->ws_io[1].p), static_cast<int32_t*>(c->ws_io[2].p), cnt, kept ? cnt + nq : nullptr,
                           raw_seen ? cnt + 2 * nq : nullptr);
     if (rc) return rc;
+    // a query whose HashMap would have treeified a bin (count = -1) is finished by the literal JDK model on the host (rare path)
+    rc = guarded([&]() -> int {
+        return resolve_unmodelled(c, nq, static_cast<const uint64_t*>(c->ws_io[0].p), probe_override, limit, cap, static_cast<int32_t*>(c->ws_io[1].p),
+                                  static_cast<int32_t*>(c->ws_io[2].p), cnt, kept ? cnt + nq : nullptr, raw_seen ? cnt + 2 * nq : nullptr, nullptr, nullptr);
+    });
+    if (rc) return rc;
     FSP_HIP(hipMemcpyAsync(ids, c->ws_io[1].p, ob, hipMemcpyDeviceToHost, c->stream));
     if (score) FSP_HIP(hipMemcpyAsync(score, c->ws_io[2].p, ob, hipMemcpyDeviceToHost, c->stream));
     FSP_HIP(hipMemcpyAsync(count, cnt, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
     if (kept) FSP_HIP(hipMemcpyAsync(kept, cnt + nq, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
     if (raw_seen) FSP_HIP(hipMemcpyAsync(raw_seen, cnt + 2 * nq, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
     FSP_HIP(hipStreamSynchronize(c->stream));
-    // all outputs are in place; a query whose HashMap would have treeified a bin carries count = -1 and fails the call loudly
+    // all outputs are in place; what is still flagged could not be finished by the host model either: a treeified bin holds
+    // different ids with EQUAL String.hashCode and the ids are not decimal ordinals, so their String.compareTo order is unknown here
     for (int64_t i = 0; i < nq; i++)
         if (count[i] < 0)
-            return fail(FSPANN_E_STATE, "query %lld: a HashMap bin of bestScore would be treeified (>= 9 candidate ids in one bin): "
-                        "the JVM's iteration order is not modelled, its count is -1", (long long)i);
+            return fail(FSPANN_E_STATE, "query %lld: a treeified HashMap bin of bestScore orders different ids with equal String.hashCode by "
+                        "String.compareTo, which the library cannot evaluate for non-decimal ids: not modelled, its count is -1", (long long)i);
     return FSPANN_OK;
 }
 
@@ -1266,7 +1303,7 @@ int fspann_refine(fspann_ctx* c, int64_t nq, const void* q, const void* cand, in
 // ---- plaintext store (test / bench harness) ----------------------------------------------
 int fspann_store_set(fspann_ctx* c, int64_t n, const void* vectors, int dtype) {
     CHECK_CTX(c);
-    if (c->share_children > 0) return fail(FSPANN_E_STATE, "the store is shared with %d clone(s): destroy them first", c->share_children);
+    if (c->share_children.load() > 0) return fail(FSPANN_E_STATE, "the store is shared with %d clone(s): destroy them first", c->share_children.load());
     if (!vectors) return fail(FSPANN_E_NULL, "vectors is null");
     if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
     if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
@@ -1287,7 +1324,7 @@ int fspann_store_set(fspann_ctx* c, int64_t n, const void* vectors, int dtype) {
 // memory alive and unchanged while the context refers to it (until the next store_set / store_attach / ctx_destroy).
 int fspann_store_attach_dev(fspann_ctx* c, int64_t n, const void* vectors_dev, int dtype) {
     CHECK_CTX(c);
-    if (c->share_children > 0) return fail(FSPANN_E_STATE, "the store is shared with %d clone(s): destroy them first", c->share_children);
+    if (c->share_children.load() > 0) return fail(FSPANN_E_STATE, "the store is shared with %d clone(s): destroy them first", c->share_children.load());
     if (!vectors_dev) return fail(FSPANN_E_NULL, "vectors is null");
     if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
     if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
@@ -1941,6 +1978,12 @@ void pipeline_stage_a(fspann_pipeline* p) {
             if (!rc) rc = fspann_encode_dev(c, s.nq, s.q_dev, FSPANN_F32, static_cast<uint64_t*>(s.codes_dev), nullptr, static_cast<int32_t*>(s.bad_dev));
             if (!rc) rc = fspann_route_dev(c, s.nq, static_cast<const uint64_t*>(s.codes_dev), -1, static_cast<int32_t>(p->B), p->B, static_cast<int32_t*>(s.sel_dev),
                                            nullptr, static_cast<int32_t*>(s.cnt_dev), nullptr, nullptr);
+            if (!rc) {      // (rare) queries whose bestScore map treeifies a bin are finished by the host model before F_q leaves the device
+                try {
+                    rc = resolve_unmodelled(c, s.nq, static_cast<const uint64_t*>(s.codes_dev), -1, static_cast<int32_t>(p->B), p->B, static_cast<int32_t*>(s.sel_dev),
+                                            nullptr, static_cast<int32_t*>(s.cnt_dev), nullptr, nullptr, nullptr, &s.unmodelled);
+                } catch (...) { rc = FSPANN_E_NOMEM; }
+            }
             if (!rc && (hipMemcpyAsync(s.sel_pin, s.sel_dev, static_cast<size_t>(s.nq) * p->B * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                         hipMemcpyAsync(s.cnt_pin, s.cnt_dev, static_cast<size_t>(s.nq) * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                         hipStreamSynchronize(c->stream) != hipSuccess)) rc = FSPANN_E_DEVICE;
@@ -2082,7 +2125,7 @@ int fspann_pipeline_submit(fspann_pipeline* p, int64_t nq, const float* q_host, 
         si = p->free_q.front(); p->free_q.pop_front();
     }
     fspann_pipeline::Slot& s = p->slot[si];
-    s.nq = nq; s.rc = 0;
+    s.nq = nq; s.rc = 0; s.unmodelled = 0;
     std::memcpy(s.q_pin, q_host, static_cast<size_t>(nq) * p->ctx->cfg.dim * 4);
     {
         std::lock_guard<std::mutex> lk(p->mu);
@@ -2106,7 +2149,9 @@ int fspann_pipeline_collect(fspann_pipeline* p, uint64_t* ticket, int64_t* nq, i
     }
     fspann_pipeline::Slot& s = p->slot[si];
     const int rc = s.rc;
-    if (ticket) *ticket = s.ticket;
+    const uint64_t tk = s.ticket;            // the slot goes back to the free list below: nothing of it is read afterwards
+    const int64_t unm = s.unmodelled;
+    if (ticket) *ticket = tk;
     if (nq) *nq = s.nq;
     if (!rc) {
         if (out_ids) std::memcpy(out_ids, s.out_ids_pin, static_cast<size_t>(s.nq) * p->k * 4);
@@ -2118,7 +2163,10 @@ int fspann_pipeline_collect(fspann_pipeline* p, uint64_t* ticket, int64_t* nq, i
         p->free_q.push_back(si);
     }
     p->cv.notify_all();
-    return rc ? fail(rc, "a pipeline stage failed for ticket %llu", (unsigned long long)s.ticket) : FSPANN_OK;
+    if (rc) return fail(rc, "a pipeline stage failed for ticket %llu", (unsigned long long)tk);
+    if (unm) return fail(FSPANN_E_STATE, "ticket %llu: %lld queries need String.compareTo of non-decimal ids inside a treeified HashMap bin "
+                         "(not modelled): their results are empty, the others are complete", (unsigned long long)tk, (long long)unm);
+    return FSPANN_OK;
 }
 
 int fspann_pipeline_stats(fspann_pipeline* p, double* route_ms, double* decrypt_ms, double* refine_ms, int64_t* batches) {
@@ -2162,7 +2210,7 @@ int fspann_eval_metrics_dev(fspann_ctx* c, int64_t n, const float* base_dev, int
                             double* ratio_dev) {
     CHECK_CTX(c);
     if (!base_dev || !q_dev || !ann_ids_dev || !gt_ids_dev || !recall_dev || !ratio_dev) return fail(FSPANN_E_NULL, "metrics buffer is null");
-    if (n <= 0 || nq < 0 || dim <= 0 || k <= 0 || k > 64 || gt_stride < k || ann_stride <= 0) return fail(FSPANN_E_ARG, "k must be in [1, 64] and gt must hold >= k ids per query");
+    if (n <= 0 || nq < 0 || dim <= 0 || k <= 0 || k > kGtMaxK || gt_stride < k || ann_stride <= 0) return fail(FSPANN_E_ARG, "k must be in [1, %d] and gt must hold >= k ids per query", kGtMaxK);
     if (nq == 0) return FSPANN_OK;
     hipLaunchKernelGGL(gt_metrics_kernel, dim3(static_cast<unsigned>(nq)), dim3(64), 0, c->stream, base_dev, n, q_dev, dim, k, ann_ids_dev, ann_stride,
                        ann_count_dev, gt_ids_dev, gt_stride, recall_dev, ratio_dev);
@@ -2377,6 +2425,60 @@ int fspann_d2h(fspann_ctx* c, void* dst, const void* src_dev, size_t bytes) {
 // HashMap<String,BitSet>(staged.size()) and stable-sorts by key, so elements with equal keys keep
 // HashMap iteration order = (bucket at the final capacity, insertion order) — the closed form used
 // here (valid while no bin treeifies; DESIGN.md "Java order key").
+}  // extern "C"
+namespace {
+// Incremental Setup: rows arrive in chunks (IndexService.insert is one vector at a time, common/.../IndexService.java:19; a JVM
+// hands over direct buffers of at most 2 GB), are coded on arrival — MFMA pre-filter + exact re-check for chunks >= 4096 rows,
+// bit-identical codes either way — and only their codes stay in HBM until the cut.
+int build_begin_impl(fspann_ctx* c, int64_t n) {
+    const size_t need = static_cast<size_t>(n) * c->TD * c->W * 8;
+    int rc = ensure(c, c->bld_codes, need);
+    if (rc) return rc;
+    c->bld_n = n;               // capacity in rows (grown by append when the hint was too small)
+    c->bld_done = 0;
+    c->frozen = false;
+    return FSPANN_OK;
+}
+int build_append_impl(fspann_ctx* c, int64_t nrows, const void* rows, int dtype) {
+    const int d = c->cfg.dim, TD = c->TD, W = c->W;
+    const size_t esz = dtype == FSPANN_F64 ? 8 : 4;
+    const int64_t chunk = 1 << 18;
+    int rc;
+    if (c->bld_done + nrows > c->bld_n) {       // more rows than the hint: grow the code buffer, keep what is coded
+        const int64_t cap = std::max<int64_t>(c->bld_done + nrows, c->bld_n + c->bld_n / 2);
+        if (cap >= (1LL << 31)) return fail(FSPANN_E_RANGE, "more than 2^31 - 1 rows");
+        const size_t row = static_cast<size_t>(TD) * W * 8;
+        void* bigger = nullptr;
+        FSP_HIP(hipMalloc(&bigger, static_cast<size_t>(cap) * row + 256));
+        if (hipMemcpyAsync(bigger, c->bld_codes.p, static_cast<size_t>(c->bld_done) * row, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipFree(bigger); return fail(FSPANN_E_DEVICE, "copy of the coded rows failed"); }
+        (void)hipFree(c->bld_codes.p);
+        c->bld_codes.p = bigger; c->bld_codes.bytes = static_cast<size_t>(cap) * row + 256; c->bld_codes.gen++;
+        c->bld_n = cap;
+    }
+    if ((rc = ensure(c, c->ws_io[0], static_cast<size_t>(std::min(chunk, nrows)) * d * esz))) return rc;
+    if ((rc = ensure(c, c->ws_io[2], static_cast<size_t>(std::min(chunk, nrows)) * 4))) return rc;
+    uint64_t* codes_all = static_cast<uint64_t*>(c->bld_codes.p);
+    std::vector<int32_t> bad(static_cast<size_t>(std::min(chunk, nrows)));
+    for (int64_t s = 0; s < nrows; s += chunk) {
+        const int64_t cn = std::min(chunk, nrows - s);
+        FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, static_cast<const char*>(rows) + static_cast<size_t>(s) * d * esz,
+                               static_cast<size_t>(cn) * d * esz, hipMemcpyHostToDevice, c->stream));
+        uint64_t* cdst = codes_all + static_cast<size_t>(c->bld_done + s) * TD * W;
+        rc = fspann_encode_dev(c, cn, c->ws_io[0].p, dtype, cdst, nullptr, static_cast<int32_t*>(c->ws_io[2].p));
+        if (rc) return rc;
+        FSP_HIP(hipMemcpyAsync(bad.data(), c->ws_io[2].p, static_cast<size_t>(cn) * 4, hipMemcpyDeviceToHost, c->stream));
+        FSP_HIP(hipStreamSynchronize(c->stream));
+        for (int64_t i = 0; i < cn; i++)
+            if (bad[i]) { const long long hb = static_cast<long long>(c->bld_done + s + i); c->bld_done = -1; return fail(FSPANN_E_ARG, "Vector contains NaN/Inf (handle %lld)", hb); }
+    }
+    c->bld_done += nrows;
+    return FSPANN_OK;
+}
+int build_finish_impl(fspann_ctx* c, const int32_t* order);
+}  // namespace
+extern "C" {
+
 int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype, const int32_t* order) {
     CHECK_CTX(c);
     CHECK_UNSHARED(c);
@@ -2385,13 +2487,56 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
     if (n <= 0) return fail(FSPANN_E_ARG, "n <= 0");
     if (c->n_ids < n) return fail(FSPANN_E_STATE, "set id metadata for at least n handles first");
     if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
-    const int d = c->cfg.dim, TD = c->TD, W = c->W, S = c->cfg.block_size;
-    const size_t esz = dtype == FSPANN_F64 ? 8 : 4;
-    c->frozen = false;
     return guarded([&]() -> int {
+        int rc = build_begin_impl(c, n);
+        if (!rc) rc = build_append_impl(c, n, vectors, dtype);
+        if (!rc) rc = build_finish_impl(c, order);
+        c->bld_done = -1;
+        return rc;
+    });
+}
+
+// The same Setup with the rows handed over in pieces (include/fspann.h).
+int fspann_build_begin(fspann_ctx* c, int64_t n_total) {
+    CHECK_CTX(c);
+    CHECK_UNSHARED(c);
+    if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized");
+    if (n_total <= 0 || n_total >= (1LL << 31)) return fail(FSPANN_E_ARG, "n_hint out of range");
+    return guarded([&]() -> int { return build_begin_impl(c, n_total); });
+}
+int fspann_build_append(fspann_ctx* c, int64_t n_rows, const void* rows, int dtype) {
+    CHECK_CTX(c);
+    CHECK_UNSHARED(c);
+    if (c->bld_done < 0) return fail(FSPANN_E_STATE, "no build in progress (fspann_build_begin)");
+    if (n_rows < 0) return fail(FSPANN_E_ARG, "n_rows < 0");
+    if (n_rows == 0) return FSPANN_OK;
+    if (!rows) return fail(FSPANN_E_NULL, "vector cannot be null");
+    if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+    return guarded([&]() -> int { return build_append_impl(c, n_rows, rows, dtype); });
+}
+int fspann_build_finish(fspann_ctx* c, const int32_t* order) {
+    CHECK_CTX(c);
+    CHECK_UNSHARED(c);
+    if (c->bld_done < 0) return fail(FSPANN_E_STATE, "no build in progress (fspann_build_begin)");
+    if (c->bld_done == 0) return fail(FSPANN_E_STATE, "no rows appended");
+    if (c->n_ids < c->bld_done) return fail(FSPANN_E_STATE, "%lld rows appended but id metadata covers %lld handles (fspann_set_id_meta)", (long long)c->bld_done, (long long)c->n_ids);
+    return guarded([&]() -> int {
+        c->bld_n = c->bld_done;     // the rows appended are the index
+        const int rc = build_finish_impl(c, order);
+        c->bld_done = -1;
+        return rc;
+    });
+}
+
+}  // extern "C"
+namespace {
+int build_finish_impl(fspann_ctx* c, const int32_t* order) {
+    const int64_t n = c->bld_n;
+    const int TD = c->TD, W = c->W, S = c->cfg.block_size;
+    int rc;
     std::vector<int32_t> ord(static_cast<size_t>(n));
     if (order) {
-        // order[] is a permutation of the n handles whose rows `vectors` holds: a handle >= n has no row (and no code),
+        // order[] is a permutation of the n handles whose rows were appended: a handle >= n has no row (and no code),
         // a repeated handle would put an id twice into every table
         std::copy(order, order + n, ord.begin());
         std::vector<uint64_t> seen(static_cast<size_t>((n + 63) / 64), 0ull);
@@ -2410,30 +2555,13 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
             for (int64_t i = 0; i < ms - 1; i++) ord[k++] = static_cast<int32_t>(i);
         }
     }
-    // 1) codes for every handle (row h of `vectors`), in chunks; they stay in HBM (codes_all[h][td][w]) for the cut
+    // 1) the codes of every handle are in HBM (codes_all[h][td][w]); the host cut wants them on the host
     const bool gpu_cut = c->knob_gpu_cut != 0;
+    uint64_t* codes_all = static_cast<uint64_t*>(c->bld_codes.p);
     std::vector<uint64_t> codes(gpu_cut ? 0 : static_cast<size_t>(n) * TD * W);
-    const int64_t chunk = 1 << 18;
-    int rc;
-    if ((rc = ensure(c, c->ws_io[0], static_cast<size_t>(std::min(chunk, n)) * d * esz))) return rc;
-    if ((rc = ensure(c, c->ws_io[1], gpu_cut ? static_cast<size_t>(n) * TD * W * 8 : static_cast<size_t>(std::min(chunk, n)) * TD * W * 8))) return rc;
-    if ((rc = ensure(c, c->ws_io[2], static_cast<size_t>(std::min(chunk, n)) * 4))) return rc;
-    uint64_t* codes_all = static_cast<uint64_t*>(c->ws_io[1].p);
-    std::vector<int32_t> bad(static_cast<size_t>(std::min(chunk, n)));
-    for (int64_t s = 0; s < n; s += chunk) {
-        const int64_t cn = std::min(chunk, n - s);
-        FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, static_cast<const char*>(vectors) + static_cast<size_t>(s) * d * esz,
-                               static_cast<size_t>(cn) * d * esz, hipMemcpyHostToDevice, c->stream));
-        uint64_t* cdst = gpu_cut ? codes_all + static_cast<size_t>(s) * TD * W : codes_all;
-        rc = fspann_encode_dev(c, cn, c->ws_io[0].p, dtype, cdst, nullptr, static_cast<int32_t*>(c->ws_io[2].p));
-        if (rc) return rc;
-        if (!gpu_cut)
-            FSP_HIP(hipMemcpyAsync(codes.data() + static_cast<size_t>(s) * TD * W, cdst, static_cast<size_t>(cn) * TD * W * 8,
-                                   hipMemcpyDeviceToHost, c->stream));
-        FSP_HIP(hipMemcpyAsync(bad.data(), c->ws_io[2].p, static_cast<size_t>(cn) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (!gpu_cut) {
+        FSP_HIP(hipMemcpyAsync(codes.data(), codes_all, codes.size() * 8, hipMemcpyDeviceToHost, c->stream));
         FSP_HIP(hipStreamSynchronize(c->stream));
-        for (int64_t i = 0; i < cn; i++)
-            if (bad[i]) return fail(FSPANN_E_ARG, "Vector contains NaN/Inf (handle %lld)", (long long)(s + i));
     }
     // 2) per table: order by (key, HashMap bucket, insertion position), cut blocks of S
     const int capf = java_final_cap_host(table_size_for(static_cast<int>(std::min<int64_t>(n, 1 << 30))), n);
@@ -2446,19 +2574,18 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
     // The closed form "iteration order = (bucket at the final capacity, insertion order)" holds only while no bin of
     // HashMap<String,BitSet>(staged.size()) (PIS:413, idx/GreedyPartitioner.java:45-48) is treeified: a put that finds 8
     // nodes in its bin (table >= 64) turns the bin into a red-black tree whose iteration order is not insertion order.
-    // Replay the bin occupancy put by put, capacity stage by capacity stage, and refuse loudly instead of cutting
-    // partitions in an order the JVM would not produce.
+    // Replay the bin occupancy put by put, capacity stage by capacity stage; when a bin does treeify, the iteration order
+    // of the staging map comes from the literal JDK model (host/java_hashmap.hpp) instead of the closed form.
+    bool tree_bins = false;
     {
         int cap = table_size_for(static_cast<int>(std::min<int64_t>(n, 1 << 30)));
         int64_t thr = static_cast<int64_t>(static_cast<float>(cap) * 0.75f);
         std::vector<uint8_t> occ(static_cast<size_t>(cap), 0);
-        for (int64_t i = 0; i < n; i++) {
+        for (int64_t i = 0; i < n && !tree_bins; i++) {
             uint32_t h = static_cast<uint32_t>(c->h_java_hash[ord[i]]);
             h ^= (h >> 16);
             uint8_t& o = occ[h & static_cast<uint32_t>(cap - 1)];
-            if (o >= 8 && cap >= 64)
-                return fail(FSPANN_E_STATE, "HashMap bin treeified while staging id handle %d (9 ids in one bin at table length %d): "
-                            "the JVM's iteration order is not modelled, import the partitions with fspann_set_index instead", ord[i], cap);
+            if (o >= 8 && cap >= 64) { tree_bins = true; break; }
             if (o < 255) o++;
             if (i + 1 > thr && cap < (1 << 30)) {      // ++size > threshold -> resize(): every bin splits in two
                 const int oldCap = cap;
@@ -2473,6 +2600,19 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
                 }
             }
         }
+    }
+    std::vector<uint32_t> iter_pos;        // tree_bins: staged positions in the map's iteration order
+    if (tree_bins) {
+        jdk::HashMapModel<replay::KeyOrderView> mp(static_cast<int32_t>(std::min<int64_t>(n, INT32_MAX)), replay::KeyOrderView{c->decimal_ids});
+        mp.reserve(static_cast<size_t>(n));
+        for (int64_t i = 0; i < n; i++) mp.put(ord[i], c->h_java_hash[ord[i]], i);
+        if (mp.unmodelled)
+            return fail(FSPANN_E_STATE, "a treeified HashMap bin of the staging map holds different ids with EQUAL String.hashCode and the ids are not "
+                        "decimal ordinals: their String.compareTo order is unknown to the library, import the partitions with fspann_set_index instead");
+        iter_pos.reserve(static_cast<size_t>(n));
+        mp.for_each([&](int32_t, int64_t pos) { iter_pos.push_back(static_cast<uint32_t>(pos)); });
+        // the host cut orders by (key, bucket, position): give it the iteration RANK as the "bucket" and it needs nothing else
+        if (!gpu_cut) for (int64_t k = 0; k < n; k++) bucket[iter_pos[static_cast<size_t>(k)]] = static_cast<uint32_t>(k);
     }
     if (gpu_cut) {
         // ---- the cut on the GPU (build.hip.h): (bin, position) order once, then per table a stable radix sort by key + cut ----
@@ -2511,11 +2651,16 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
             return cur;
         };
         // (a) staged positions ordered by (bin at the map's final table length, position)
-        hipLaunchKernelGGL(build_bin_keys_kernel, dim3(eg), dim3(256), 0, c->stream, d_bucket, n, d_key[0], d_pay[0]);
-        int capbits = 0;
-        while ((1 << capbits) < capf) capbits++;
-        int cur = radix(0, 0, std::max(0, (capbits + 7) / 8 - 1));
-        FSP_HIP(hipMemcpyAsync(d_perm0, d_pay[cur], pb, hipMemcpyDeviceToDevice, c->stream));
+        int cur = 0;
+        if (tree_bins) {                // a bin treeified: the iteration order of the staging map was computed by the JDK model
+            FSP_HIP(hipMemcpyAsync(d_perm0, iter_pos.data(), pb, hipMemcpyHostToDevice, c->stream));
+        } else {
+            hipLaunchKernelGGL(build_bin_keys_kernel, dim3(eg), dim3(256), 0, c->stream, d_bucket, n, d_key[0], d_pay[0]);
+            int capbits = 0;
+            while ((1 << capbits) < capf) capbits++;
+            cur = radix(0, 0, std::max(0, (capbits + 7) / 8 - 1));
+            FSP_HIP(hipMemcpyAsync(d_perm0, d_pay[cur], pb, hipMemcpyDeviceToDevice, c->stream));
+        }
         FSP_HIP(hipGetLastError());
         // (b) per table: keys of that sequence, stable sort by key over the bytes that can differ, cut
         const int sig = std::min(63, c->bits);                  // key bits [63 - sig, 62] carry code bits
@@ -2589,7 +2734,7 @@ int fspann_build_index(fspann_ctx* c, int64_t n, const void* vectors, int dtype,
     if (worker_oom) return fail(FSPANN_E_NOMEM, "out of host memory while cutting partitions");
     c->dev_index_dirty = true;
     return fspann_finalize(c);
-    });
 }
+}  // namespace
 
-}  // extern "C"
+#include "api_ext.hip.h"

@@ -9,7 +9,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -68,6 +70,10 @@ struct DevBuf {
 
 // The opaque context of include/fspann.h.
 struct fspann_ctx {
+    // Calls on one context are serialised INSIDE the library: every entry point that takes a context holds this
+    // lock for its duration (recursive: entry points call each other).  Different contexts — e.g. the clones of one index —
+    // run concurrently.
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     fspann_cfg cfg{};
@@ -141,7 +147,11 @@ struct fspann_ctx {
     // id metadata
     int64_t n_ids = 0;
     int32_t* d_java_hash = nullptr;
-    uint32_t* d_deleted_bits = nullptr;  // nullptr => nothing deleted
+    // mirror of metadata.isDeleted (PIS:739), one bit per handle; nullptr => nothing deleted so far.  Owned by the index owner;
+    // a clone reads the OWNER's pointer at every call (fspann_set_deleted may allocate it while clones are alive), so it is atomic.
+    std::atomic<uint32_t*> d_deleted_bits{nullptr};
+    std::vector<uint32_t> h_deleted_bits;   // host mirror (owner only; guarded by deleted_mu): the host replay of a query reads it
+    std::mutex deleted_mu;
     std::vector<int32_t> h_java_hash;
     bool decimal_ids = false;  // ids are Long.toString(handle): String.hashCode computed in-kernel
 
@@ -172,8 +182,12 @@ struct fspann_ctx {
     // fspann_ctx_clone: a clone reads its parent's GFunctions, frozen index, id metadata and store in place (no second copy in
     // HBM, and ONE working set in the caches however many contexts serve it); it owns its stream and work areas.
     fspann_ctx* share_parent = nullptr;  // non-null: the index arrays above belong to that context
-    int share_children = 0;              // clones alive; the shared state may not change while > 0
+    std::atomic<int> share_children{0};  // clones alive; the shared state may not change while > 0 (changed under the owner's `mu`)
     bool zombie = false;                 // destroyed by its owner while clones were alive: freed with the last clone
+    std::atomic<int> comm_refs{0};       // fspann_comm objects that hold this context (it must outlive them)
+    // incremental Setup (fspann_build_begin / _append / _finish): codes of the rows appended so far stay in HBM
+    int64_t bld_n = 0, bld_done = -1;    // bld_done < 0: no build in progress
+    fspann::DevBuf bld_codes;
 };
 
 namespace fspann {

@@ -153,37 +153,39 @@ __global__ __launch_bounds__(64) void gt_metrics_kernel(const float* __restrict_
     }
     for (int off = 32; off > 0; off >>= 1) hits += __shfl_xor(hits, off);
     // ratio: needs k results; BaseVectorReader.l2 = sqrt(sum (q_i - v_i)^2), q widened to double first (FSA:1017-1073)
-    double sum = 0.0;
-    int used = 0;
-    if (na >= k) {
-        const float* qr = q + qi * d;
-        for (int i = lane; i < k; i += 64) {
-            const int32_t ai = a[i], gi = g[i];
-            if (ai < 0 || ai >= n || gi < 0 || gi >= n) continue;
-            double sg = 0.0, sa = 0.0;
-            for (int t = 0; t < d; t++) {
-                const double qv = static_cast<double>(qr[t]);
-                const double dg = qv - static_cast<double>(base[static_cast<int64_t>(gi) * d + t]);
-                const double pg = dg * dg;
-                sg = sg + pg;
-                const double da = qv - static_cast<double>(base[static_cast<int64_t>(ai) * d + t]);
-                const double pa = da * da;
-                sa = sa + pa;
-            }
-            const double dGt = sqrt(sg);
-            if (!(dGt > 0)) continue;
-            sum += sqrt(sa) / dGt;
-            used++;
-        }
-    }
-    // the reference adds the k terms in index order; here lanes hold interleaved subsets -> fold them in index order too:
-    // with k <= 64 every lane holds at most one term, so a sequential fold over lanes reproduces the Java sum exactly
+    // the reference adds the k terms in index order: rounds of 64 terms, lane l holds term 64 r + l, and a sequential fold over
+    // the lanes inside every round reproduces the Java sum exactly (any k)
     double tot = 0.0;
     int usedt = 0;
-    for (int l = 0; l < 64; l++) {
-        const double v = __shfl(sum, l);
-        const int u = __shfl(used, l);
-        if (u) { tot = tot + v; usedt += u; }
+    if (na >= k) {
+        const float* qr = q + qi * d;
+        for (int i0 = 0; i0 < k; i0 += 64) {
+            const int i = i0 + lane;
+            double term = 0.0;
+            int used = 0;
+            if (i < k) {
+                const int32_t ai = a[i], gi = g[i];
+                if (!(ai < 0 || ai >= n || gi < 0 || gi >= n)) {
+                    double sg = 0.0, sa = 0.0;
+                    for (int t = 0; t < d; t++) {
+                        const double qv = static_cast<double>(qr[t]);
+                        const double dg = qv - static_cast<double>(base[static_cast<int64_t>(gi) * d + t]);
+                        const double pg = dg * dg;
+                        sg = sg + pg;
+                        const double da = qv - static_cast<double>(base[static_cast<int64_t>(ai) * d + t]);
+                        const double pa = da * da;
+                        sa = sa + pa;
+                    }
+                    const double dGt = sqrt(sg);
+                    if (dGt > 0) { term = sqrt(sa) / dGt; used = 1; }
+                }
+            }
+            for (int l = 0; l < 64; l++) {
+                const double v = __shfl(term, l);
+                const int u = __shfl(used, l);
+                if (u) { tot = tot + v; usedt += u; }
+            }
+        }
     }
     if (lane == 0) {
         recall[qi] = static_cast<double>(hits) / static_cast<double>(k);

@@ -337,6 +337,7 @@ struct fspann_pipeline {
         void *q_dev = nullptr, *codes_dev = nullptr, *sel_dev = nullptr, *cnt_dev = nullptr, *cand_dev = nullptr, *ids_dev = nullptr, *kcnt_dev = nullptr,
              *oi_dev = nullptr, *od_dev = nullptr, *oc_dev = nullptr, *bad_dev = nullptr;
         int rc = 0;
+        int64_t unmodelled = 0;          // queries of this batch the host model could not finish either (count stays -1: empty result)
         double t_route_ms = 0, t_decrypt_ms = 0, t_refine_ms = 0;
     };
     fspann_ctx* ctx = nullptr;

@@ -151,6 +151,26 @@ class FspannContext:
         o = None if order is None else _c(order, np.int32)
         N.check(self.L.fspann_build_index(self._h, v.shape[0], _p(v), _dt(v), _p(o)))
 
+    def build_begin(self, n_total: int):
+        """Incremental Setup: begin(n) -> append(rows of the next handles) ... -> finish(order) (fspann_build_begin / _append / _finish)."""
+        N.check(self.L.fspann_build_begin(self._h, int(n_total)))
+
+    def build_append(self, rows):
+        v = np.ascontiguousarray(rows)
+        if v.dtype not in (np.float32, np.float64):
+            v = v.astype(np.float64)
+        v = v.reshape(-1, self.cfg.dim)
+        N.check(self.L.fspann_build_append(self._h, v.shape[0], _p(v), _dt(v)))
+
+    def build_finish(self, order=None):
+        o = None if order is None else _c(order, np.int32)
+        N.check(self.L.fspann_build_finish(self._h, _p(o)))
+
+    def set_deleted(self, handles, flag=True):
+        """Live mirror of metadata.isDeleted (PIS:739): no un-freeze, works on the owner or any clone while they serve queries."""
+        h = _c(handles, np.int32).reshape(-1)
+        N.check(self.L.fspann_set_deleted(self._h, _p(h), len(h), 1 if flag else 0))
+
     def save_index(self, path: str):
         N.check(self.L.fspann_index_save(self._h, os.fsencode(path)))
 
@@ -236,6 +256,31 @@ class FspannContext:
             return dict(ids=ids, score=score, count=count)
         return dict(ids=ids, score=score, count=count, kept=kept, raw_seen=raw)
 
+    def route_flags(self, codes, probe_override=-1):
+        """Diagnostics: which queries the full select FLAGS (count = -1: a HashMap bin of bestScore would be treeified) before the
+        host model finishes them — fspann_route_dev with the counters requested (exact detection), nothing resolved."""
+        codes = _c(codes, np.uint64).reshape(-1, self.TD, self.W)
+        nq = codes.shape[0]
+        cap = max(1, self.route_max_candidates(probe_override))
+        bufs = []
+
+        def dev(nbytes):
+            p = C.c_void_p()
+            N.check(self.L.fspann_dev_alloc(self._h, nbytes, C.byref(p)))
+            bufs.append(p)
+            return p
+        try:
+            d_codes, d_ids, d_cnt, d_kept = dev(codes.nbytes), dev(nq * cap * 4), dev(nq * 4), dev(nq * 4)
+            N.check(self.L.fspann_h2d(self._h, d_codes, _p(codes), codes.nbytes))
+            N.check(self.L.fspann_route_dev(self._h, nq, d_codes, probe_override, N.INT32_MAX, cap, d_ids, None, d_cnt, d_kept, None))
+            count = np.zeros(nq, np.int32)
+            N.check(self.L.fspann_d2h(self._h, _p(count), d_cnt, nq * 4))
+            self.unmodelled_queries(reset=True)
+        finally:
+            for p in bufs:
+                self.L.fspann_dev_free(self._h, p)
+        return count < 0
+
     # -- Refine ----------------------------------------------------------------------
     def refine(self, q, cand, cand_ids, cand_count, k):
         cand = np.ascontiguousarray(cand)
@@ -302,6 +347,21 @@ class FspannContext:
     def route_dev(self, nq, codes_ptr, probe_override, limit, cap, ids_ptr, score_ptr, count_ptr, kept_ptr, raw_ptr):
         N.check(self.L.fspann_route_dev(self._h, nq, codes_ptr, probe_override, limit, cap, ids_ptr, score_ptr or None,
                                         count_ptr, kept_ptr or None, raw_ptr or None))
+
+    def route_resolve_dev(self, nq, codes_ptr, probe_override, limit, cap, ids_ptr, score_ptr, count_ptr, kept_ptr=0, raw_ptr=0) -> int:
+        """Finish the queries an asynchronous Route call flagged (count -1: a HashMap bin treeified) with the host model; returns how many."""
+        done = C.c_int64(0)
+        N.check(self.L.fspann_route_resolve_dev(self._h, nq, codes_ptr, probe_override, limit, cap, ids_ptr, score_ptr or None, count_ptr,
+                                                kept_ptr or None, raw_ptr or None, C.byref(done)))
+        return int(done.value)
+
+    def search_store_finish_dev(self, nq, q_ptr, q_dtype, probe_override, B, k, out_ids_ptr, out_dist_ptr, out_count_ptr, scored_ptr=0,
+                                sel_ids_ptr=0, sel_count_ptr=0) -> int:
+        """Completes the preceding search_store_dev call: flagged queries are finished on the host and the batch is scored again."""
+        done = C.c_int64(0)
+        N.check(self.L.fspann_search_store_finish_dev(self._h, nq, q_ptr, q_dtype, probe_override, B, k, out_ids_ptr, out_dist_ptr, out_count_ptr,
+                                                      scored_ptr or None, sel_ids_ptr or None, sel_count_ptr or None, C.byref(done)))
+        return int(done.value)
 
     def store_gather_dev(self, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr):
         N.check(self.L.fspann_store_gather_dev(self._h, nq, sel_ids_ptr, sel_count_ptr, B, cand_ptr))

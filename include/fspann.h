@@ -25,8 +25,10 @@
  *   - ids are int32 handles.  The Java adapter keeps String id <-> handle and
  *     hands String.hashCode() per handle to fspann_set_id_meta (it decides the
  *     reference's HashMap iteration order, see DESIGN.md "Java order key").
- *   - one context = one GPU = one stream; calls on a context are serialised by
- *     the caller (QueryServiceImpl is not re-entrant either, QSI:45-64).
+ *   - one context = one GPU = one stream; calls on a context are serialised INSIDE
+ *     the library (a per-context lock held for the duration of every entry point), so
+ *     a context shared between threads is safe, just not parallel — use
+ *     fspann_ctx_clone for that (QueryServiceImpl is not re-entrant either, QSI:45-64).
  * ========================================================================== */
 #ifndef FSPANN_H
 #define FSPANN_H
@@ -120,6 +122,23 @@ int fspann_finalize(fspann_ctx* ctx);
  * host, row h = handle h.  Requires set_gfunctions + set_id_meta first.  Freezes ctx.     */
 int fspann_build_index(fspann_ctx* ctx, int64_t n, const void* vectors, int dtype, const int32_t* order);
 
+/* The same Setup with the rows handed over in PIECES: IndexService.insert(String, double[]) is one vector at a time
+ * (common/.../IndexService.java:19, PIS:265-347) and a JVM's direct buffers hold at most 2 GB, while config #3 / #4 hand over
+ * 7.7 / 30.7 GB of rows.  begin(n_hint) -> append(rows of the next n_rows handles, fp32 or fp64; any chunk size) ... ->
+ * finish(order): every chunk is coded on arrival and only its codes (T*D*W*8 bytes per row) stay in HBM; finish cuts the
+ * partitions over the rows appended and freezes the context exactly as fspann_build_index does (which is begin + one append +
+ * finish).  n_hint sizes the code buffer (the exact total avoids a regrow; more rows than hinted are accepted).  Needs
+ * fspann_set_gfunctions before begin and fspann_set_id_meta (for >= the rows appended) before finish.               */
+int fspann_build_begin(fspann_ctx* ctx, int64_t n_hint);
+int fspann_build_append(fspann_ctx* ctx, int64_t n_rows, const void* rows, int dtype);
+int fspann_build_finish(fspann_ctx* ctx, const int32_t* order);
+
+/* Live mirror of metadata.isDeleted(id) (PIS:739: asked for every id of every probed partition at query time, so a delete shows in
+ * the next query).  Sets (flag != 0) or clears the deleted bit of `handles[0..n)` WITHOUT un-freezing the context; may be called
+ * on the index owner or on any of its clones while all of them serve queries: Route calls enqueued after it returns see the
+ * change, calls in flight see the old or the new flag (as a JVM query racing a delete does).                      */
+int fspann_set_deleted(fspann_ctx* ctx, const int32_t* handles, int64_t n, int flag);
+
 /* Frozen-index file: GFunctions + id metadata + every table as flat little-endian SoA.  The reference
  * never persists routing state and rebuilds it by decrypting every point (ForwardSecureANNSystem.java:926-948).
  * load() requires a context created with the same tables/divisions/m/lambda/dim and freezes it.              */
@@ -164,14 +183,26 @@ int fspann_route_dev(fspann_ctx* ctx, int64_t nq, const uint64_t* codes_dev, int
 /* JDK HashMap order and its limit.  The list order above is the iteration order of HashMap<String,Long> bestScore
  * (PIS:619,690-693) stable-sorted by score; the library derives it in closed form (bin index at the map's final table
  * length, then first insertion) — exact while every bin is a plain chain.  A put that finds 8 nodes in its bin makes the
- * JVM treeify that bin, after which its iteration order is NOT modelled.  That case is detected exactly (per capacity
- * stage of the map) and fails loudly instead of returning a non-Java order: the query's count is set to -1 (Refine then
- * scores nothing for it), fspann_route returns FSPANN_E_STATE after writing all outputs, and for the asynchronous _dev
- * entry points fspann_unmodelled_queries reports how many queries were flagged since the last reset (synchronises).
- * fspann_build_index applies the same rule to HashMap<String,BitSet>(staged.size()) (PIS:413) and returns FSPANN_E_STATE.
+ * JVM treeify that bin, after which the closed form no longer holds.  That case is detected exactly on the GPU (per capacity
+ * stage of the map): the query's count is set to -1 (Refine scores nothing for it) and it is handed to the host model below —
+ * fspann_route finishes it before it returns; after the asynchronous _dev entry points fspann_unmodelled_queries reports how
+ * many queries are flagged (synchronises) and fspann_route_resolve_dev finishes them.
+ * fspann_build_index applies the same rule to HashMap<String,BitSet>(staged.size()) (PIS:413): when a bin of the staging map
+ * treeifies, the map's iteration order comes from the host model instead of the GPU's (bin, position) sort.
  * The bounded select hands a query to the full select when >= 9 of the entries it holds share (score, bin); a bin that
  * reaches 9 ids only through candidates the bounded select never loads is not seen by it ("treeified bins"). */
 int fspann_unmodelled_queries(fspann_ctx* ctx, int64_t* total, int reset);
+/* Answer the flagged queries instead of refusing them.  A treeified bin's iteration order is java.util.HashMap.TreeNode's `next`
+ * list (treeify keeps the chain order and moves the root to the front, putTreeVal links a new node behind its tree parent, resize
+ * splits in order and untreeifies at <= 6): the library carries a literal host model of that (host/java_hashmap.hpp) and replays a
+ * flagged query's lookupCandidatesWithScores put by put (host/route_replay.hpp) — the rare path, ~0.3 % of the queries at the
+ * reference's shipped profiles.  fspann_route does this by itself.  After an asynchronous fspann_route_dev / fspann_tick_dev call,
+ * fspann_route_resolve_dev (same arguments as that call) synchronises the stream, finishes every query whose count is -1 and
+ * rewrites its ids / score / count / kept / raw_seen in place; *resolved = how many.  What stays -1 afterwards: a tree bin that
+ * must order different ids with EQUAL String.hashCode (String.compareTo) when the ids are not decimal ordinals.              */
+int fspann_route_resolve_dev(fspann_ctx* ctx, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit, int64_t cap,
+                             int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev, int32_t* raw_seen_dev,
+                             int64_t* resolved);
 /* Worst-case entries per query for (probes): min(T*D*probes*block_size, HARD_CAP + block_size - 1). */
 int64_t fspann_route_max_candidates(fspann_ctx* ctx, int probe_override);
 int fspann_effective_probes(fspann_ctx* ctx, int probe_override); /* PIS:880-888 */
@@ -231,6 +262,11 @@ int fspann_refine_store_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int 
 int fspann_search_store_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtype, int probe_override, int64_t B,
                             int k, int32_t* out_ids_dev, double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev,
                             int32_t* sel_ids_dev, int32_t* sel_count_dev, int32_t* bad_dev);
+/* Completes the fspann_search_store_dev call that precedes it on this context (same arguments): synchronises, finishes the
+ * queries Route flagged (count -1, see fspann_route_resolve_dev) and, when there were any, scores the batch again.            */
+int fspann_search_store_finish_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtype, int probe_override, int64_t B, int k,
+                                   int32_t* out_ids_dev, double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev,
+                                   int32_t* sel_ids_dev, int32_t* sel_count_dev, int64_t* resolved);
 const void* fspann_store_dev_ptr(fspann_ctx* ctx, int* dtype);
 
 /* ---- one launch for three stages of three batches in flight --------------------------------------------------------------

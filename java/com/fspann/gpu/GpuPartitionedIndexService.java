@@ -45,11 +45,20 @@ public final class GpuPartitionedIndexService implements IndexService, AutoClose
     private int dim = -1, tables, divisions, m, lambda, words;
     private final List<String> idOf = new ArrayList<>();
     private final Map<String, Integer> handleOf = new HashMap<>();
-    private final List<double[]> vectors = new ArrayList<>();     // plaintext rows in insertion order, until finalizeForSearch
+    // Plaintext rows never pile up in the JVM heap: they go to a fixed direct buffer (CHUNK_BYTES) that is handed to
+    // fspann_build_append whenever it is full — the library codes each piece on arrival and keeps only the codes in HBM.
+    // Until the registry exists (the first MIN_SAMPLE_SIZE - 1 inserts, PIS:280-312) the rows are parked here, as the
+    // reference parks them in pendingVectors.
+    private static final long CHUNK_BYTES = 64L << 20;
+    private final List<double[]> parked = new ArrayList<>();
+    private ByteBuffer chunk;
+    private int chunkRows = 0, chunkCap = 0;
+    private long appended = 0;
     private volatile boolean frozen = false;
     private final ThreadLocal<Integer> probeOverride = ThreadLocal.withInitial(() -> -1);      // PIS:68-73
     private final ThreadLocal<Set<String>> lastTouched = ThreadLocal.withInitial(HashSet::new);
     private volatile int lastRawVisited = 0;                                                      // PIS:63 (shared, as in the reference)
+    private volatile boolean countersWanted = true;     // lastRawVisited / lastCandKept are profiler fields: see setCountersWanted
 
     public GpuPartitionedIndexService(PartitionedIndexService host, SystemConfig cfg, int device) {
         this.host = java.util.Objects.requireNonNull(host, "host");
@@ -57,25 +66,15 @@ public final class GpuPartitionedIndexService implements IndexService, AutoClose
         this.device = device;
     }
 
-    private static ByteBuffer buf(long bytes) {
+    /** Direct buffer in native order; a size that does not fit a Java buffer is a caller bug, not something to truncate. */
+    static ByteBuffer buf(long bytes) {
+        if (bytes < 0 || bytes > Integer.MAX_VALUE)
+            throw new IllegalArgumentException("direct buffer of " + bytes + " bytes: hand the data over in pieces");
         return ByteBuffer.allocateDirect((int) bytes).order(ByteOrder.nativeOrder());
     }
 
-    // ---- IndexService ------------------------------------------------------------------------------------------------
-    @Override public void insert(String id, double[] vector) {
-        host.insert(id, vector);                          // validation, sample buffer, encrypt, persist: PIS:265-347
-        synchronized (this) {
-            if (frozen) throw new IllegalStateException("Index already finalized");
-            if (dim < 0) dim = vector.length;
-            handleOf.put(id, idOf.size());
-            idOf.add(id);
-            vectors.add(vector.clone());
-        }
-    }
-
-    @Override public synchronized void finalizeForSearch() {
-        host.finalizeForSearch();                         // flushes the parked points, initialises GFunctionRegistry (PIS:789-845)
-        if (frozen) return;
+    /** Native context + the JVM's own GFunctions, as soon as GFunctionRegistry is initialised. */
+    private void openNative() {
         SystemConfig.PaperConfig pc = cfg.getPaper();
         tables = pc.getTables(); divisions = pc.getDivisions(); m = pc.getM(); lambda = pc.getLambda();
         words = (m * lambda + 63) / 64;
@@ -97,18 +96,70 @@ public final class GpuPartitionedIndexService implements IndexService, AutoClose
                 }
             }
         FspannNative.check(FspannNative.setGfunctions(ctx, a, r, w));
+        chunkCap = (int) Math.max(1, Math.min(CHUNK_BYTES / (8L * dim), 1 << 20));
+        chunk = buf(8L * chunkCap * dim);
+        FspannNative.check(FspannNative.buildBegin(ctx, Math.max(chunkCap, 1 << 20)));   // a hint: the code buffer grows with the rows
+        for (double[] v : parked) appendRow(v);            // handles are insertion numbers: rows go over in insertion order
+        parked.clear();
+    }
+
+    private void appendRow(double[] v) {
+        for (double x : v) chunk.putDouble(x);
+        if (++chunkRows == chunkCap) flushChunk();
+    }
+
+    private void flushChunk() {
+        if (chunkRows == 0) return;
+        FspannNative.check(FspannNative.buildAppend(ctx, chunkRows, chunk, FspannNative.F64));
+        appended += chunkRows;
+        chunkRows = 0;
+        chunk.clear();
+    }
+
+    // ---- IndexService ------------------------------------------------------------------------------------------------
+    @Override public void insert(String id, double[] vector) {
+        host.insert(id, vector);                          // validation, sample buffer, encrypt, persist: PIS:265-347
+        synchronized (this) {
+            if (frozen) throw new IllegalStateException("Index already finalized");
+            if (dim < 0) dim = vector.length;
+            handleOf.put(id, idOf.size());
+            idOf.add(id);
+            if (ctx == 0 && GFunctionRegistry.isInitialized()) openNative();
+            if (ctx != 0) appendRow(vector); else parked.add(vector.clone());
+        }
+    }
+
+    @Override public synchronized void finalizeForSearch() {
+        host.finalizeForSearch();                         // flushes the parked points, initialises GFunctionRegistry (PIS:789-845)
+        if (frozen) return;
+        if (ctx == 0) openNative();                       // fewer than MIN_SAMPLE_SIZE inserts: the registry exists only now
+        flushChunk();
         int n = idOf.size();
         ByteBuffer jh = buf(4L * n);
         for (String id : idOf) jh.putInt(id.hashCode());           // decides HashMap iteration order (DESIGN.md "Java order key")
         FspannNative.check(FspannNative.setIdMeta(ctx, n, jh, null));
-        ByteBuffer rows = buf(8L * n * dim);
-        for (double[] v : vectors) for (double x : v) rows.putDouble(x);
-        // coding + GreedyPartitioner.build on the GPU, staged order = the reference's (null); throws IllegalStateException
-        // if a HashMap bin would be treeified (iteration order then not reproducible): fall back to the host class then
-        FspannNative.check(FspannNative.buildIndex(ctx, n, rows, FspannNative.F64, null));
-        vectors.clear();
+        // GreedyPartitioner.build on the GPU over the coded rows, staged order = the reference's (null).  A staging map that
+        // treeifies a bin is ordered by the library's JDK model; only equal hashCodes of non-decimal ids inside such a bin make
+        // it throw IllegalStateException (String.compareTo unknown to it): fall back to the host class then.
+        FspannNative.check(FspannNative.buildFinish(ctx, null));
+        chunk = null;
         frozen = true;
     }
+
+    /** Mirror of metadata.isDeleted(id) (PIS:739): call beside the metadata update that marks / unmarks a point as deleted.
+     *  Takes effect for the next query, on this service and on every clone of its native context; nothing is un-frozen. */
+    public void markDeleted(String id, boolean deleted) {
+        Integer h = handleOf.get(id);
+        if (h == null || ctx == 0) return;
+        ByteBuffer hb = buf(4);
+        hb.putInt(0, h);
+        FspannNative.check(FspannNative.setDeleted(ctx, hb, 1, deleted ? 1 : 0));
+    }
+
+    /** lastCandKept / getLastRawCandidateCount are profiler fields of the reference (QSI:417-474).  Producing them forces the
+     *  full select over every probed partition (2.5 x the bounded select): ask for them only while a profiler reads them. */
+    public void setCountersWanted(boolean wanted) { countersWanted = wanted; }
+    boolean countersWanted() { return countersWanted; }
 
     @Override public void updateCachedPoint(EncryptedPoint point) { host.updateCachedPoint(point); }
     @Override public EncryptedPointBuffer getPointBuffer() { return host.getPointBuffer(); }
@@ -145,7 +196,9 @@ public final class GpuPartitionedIndexService implements IndexService, AutoClose
         long cap = Math.max(1, Math.min((long) limit, FspannNative.routeMaxCandidates(ctx, po)));
         ByteBuffer ids = buf(4 * cap), sc = buf(4 * cap), cnt = buf(4);
         ByteBuffer kept = withCounters ? buf(4) : null, raw = withCounters ? buf(4) : null;
-        FspannNative.check(FspannNative.route(ctx, 1, c, po, limit, cap, ids, sc, cnt, kept, raw));   // count -1 (treeified bin) -> IllegalStateException
+        // a query whose bestScore map treeifies a bin is finished by the library's JDK model inside this call; IllegalStateException
+        // only for equal hashCodes of non-decimal ids inside such a bin (String.compareTo unknown to the library)
+        FspannNative.check(FspannNative.route(ctx, 1, c, po, limit, cap, ids, sc, cnt, kept, raw));
         int n = cnt.getInt(0);
         Set<String> touched = lastTouched.get();
         touched.clear();

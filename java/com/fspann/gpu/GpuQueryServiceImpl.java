@@ -12,7 +12,6 @@ import com.fspann.query.core.QueryTokenFactory;
 import com.fspann.query.service.QueryService;
 
 import java.nio.ByteBuffer;
-import java.nio.ByteOrder;
 import java.util.ArrayList;
 import java.util.Collections;
 import java.util.HashSet;
@@ -51,7 +50,7 @@ public final class GpuQueryServiceImpl implements QueryService {
         this.cfg = java.util.Objects.requireNonNull(cfg, "cfg");
     }
 
-    private static ByteBuffer buf(long bytes) { return ByteBuffer.allocateDirect((int) bytes).order(ByteOrder.nativeOrder()); }
+    private static ByteBuffer buf(long bytes) { return GpuPartitionedIndexService.buf(bytes); }   // refuses sizes beyond a Java buffer
 
     private static boolean isValid(double[] v) {                                // QSI:407-413
         if (v == null) return false;
@@ -81,9 +80,12 @@ public final class GpuQueryServiceImpl implements QueryService {
                 lastEffectiveLimit = limit;
                 int[] kept = new int[1];
                 // stage A + A.5 on the GPU: the first `limit` entries of the reference's list (HashMap order, stable by score)
-                List<GpuPartitionedIndexService.CandidateWithScore> fq = index.route(token, limit, true, kept);
-                lastCandTotal = index.getLastRawCandidateCount();
-                lastCandKept = kept[0];
+                // lastCandTotal / lastCandKept are profiler fields (QSI:417-474): requested only while index.setCountersWanted(true)
+                // — they force the full select over every probed partition; without them the bounded select runs (-1 = not collected)
+                final boolean counters = index.countersWanted();
+                List<GpuPartitionedIndexService.CandidateWithScore> fq = index.route(token, limit, counters, kept);
+                lastCandTotal = counters ? index.getLastRawCandidateCount() : -1;
+                lastCandKept = counters ? kept[0] : -1;
                 lastUniqueCandidates = fq.size();
                 if (fq.isEmpty()) { lastReturned = 0; return Collections.emptyList(); }
                 // stage B, host part — exactly the reference's loop (QSI:238-271): load, decrypt with the point's own version, validate

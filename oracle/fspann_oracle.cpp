@@ -93,17 +93,37 @@ inline int32_t java_decimal_hash(int64_t ordinal) {
 // supplied String.hashCode; values = int64).  Reproduces: lazy table allocation,
 // tableSizeFor, spread(), tail-append chains, value update in place, resize()
 // lo/hi split preserving relative order, treeifyBin() -> resize() while the table
-// is shorter than MIN_TREEIFY_CAPACITY (64).  A genuine treeification (chain
-// reaching 9 nodes with table >= 64) is NOT modelled: `unmodelled` is raised
-// and callers must treat iteration order as unpinned.
+// is shorter than MIN_TREEIFY_CAPACITY (64), and — transliterated method by method
+// from java.util.HashMap.TreeNode (JDK 21) — red-black TREE BINS: treeify,
+// putTreeVal, find, balanceInsertion, rotateLeft/Right, moveRootToFront, split,
+// untreeify.  HashIterator walks every bin through `next`, tree bins included, so
+// the iteration order of a tree bin is its `next` list: treeifyBin keeps the chain
+// order, treeify moves the root to the front, putTreeVal links a new node right
+// behind its tree PARENT, split relinks in order.
+// Keys are Strings in the reference: a tree bin orders by hash, then — String is
+// Comparable — by compareTo; tieBreakOrder (identityHashCode) is unreachable for
+// distinct Strings.  compareTo is only needed between different keys with EQUAL
+// hashCode; it is computable when the ids are the decimal ordinals
+// (`decimalKeys`), otherwise `unmodelled` is raised (the order is then unpinned).
+// `treeified` records that some bin became a tree (what the product's kernels
+// detect and hand to their host replay).  remove() is never used by the path.
 // -----------------------------------------------------------------------------
 struct JHashMap {
-    struct Node { int32_t hash; int32_t key; int64_t val; int32_t next; };
+    struct Node {
+        int32_t hash; int32_t key; int64_t val; int32_t next;
+        // TreeNode fields (LinkedHashMap.Entry's before/after are unused by a plain HashMap)
+        int32_t parent = -1, left = -1, right = -1, prev = -1;
+        bool red = false, isTree = false;
+    };
+    static constexpr int32_t NIL = -1;
+    static constexpr int TREEIFY_THRESHOLD = 8, UNTREEIFY_THRESHOLD = 6, MIN_TREEIFY_CAPACITY = 64;
     std::vector<Node> nodes;
     std::vector<int32_t> table;  // head node index per bucket, -1 = empty
     int32_t threshold = 0;
     int32_t size = 0;
-    bool unmodelled = false;
+    bool unmodelled = false;     // compareTo of two different keys with equal hashCode was needed and is unknown
+    bool treeified = false;      // some bin was turned into a tree
+    bool decimalKeys = false;    // keys are Long.toString(handle)
 
     static int32_t tableSizeFor(int32_t cap) {
         // n = -1 >>> numberOfLeadingZeros(cap - 1)
@@ -119,9 +139,220 @@ struct JHashMap {
         return static_cast<int32_t>(u ^ (u >> 16));
     }
 
-    explicit JHashMap(int32_t initialCapacity) {
+    explicit JHashMap(int32_t initialCapacity, bool decimal = false) : decimalKeys(decimal) {
         if (initialCapacity < 0) initialCapacity = 0;
         threshold = tableSizeFor(initialCapacity);  // HashMap(int): threshold holds initial cap
+    }
+
+    // compareComparables(String.class, k, x) = k.compareTo(x)
+    int compareKeys(int32_t k, int32_t x) {
+        if (!decimalKeys) { unmodelled = true; return 0; }
+        const std::string a = std::to_string(k), b = std::to_string(x);
+        const size_t lim = std::min(a.size(), b.size());
+        for (size_t i = 0; i < lim; i++)
+            if (a[i] != b[i]) return (int)(unsigned char)a[i] - (int)(unsigned char)b[i];
+        return (int)a.size() - (int)b.size();
+    }
+
+    // ---- TreeNode methods ---------------------------------------------------------------------
+    int32_t rootOf(int32_t r) const {
+        for (int32_t p;;) { if ((p = nodes[r].parent) == NIL) return r; r = p; }
+    }
+    void moveRootToFront(int32_t root) {
+        int32_t n;
+        if (root != NIL && (n = (int32_t)table.size()) > 0) {
+            int32_t index = (n - 1) & nodes[root].hash;
+            int32_t first = table[index];
+            if (root != first) {
+                int32_t rn;
+                table[index] = root;
+                int32_t rp = nodes[root].prev;
+                if ((rn = nodes[root].next) != NIL) nodes[rn].prev = rp;
+                if (rp != NIL) nodes[rp].next = rn;
+                if (first != NIL) nodes[first].prev = root;
+                nodes[root].next = first;
+                nodes[root].prev = NIL;
+            }
+        }
+    }
+    int32_t treeFind(int32_t start, int32_t h, int32_t k) {     // TreeNode.find(h, k, kc) with kc = String.class
+        int32_t p = start;
+        do {
+            int32_t ph, pl = nodes[p].left, pr = nodes[p].right, q;
+            int dir;
+            if ((ph = nodes[p].hash) > h) p = pl;
+            else if (ph < h) p = pr;
+            else if (nodes[p].key == k) return p;
+            else if (pl == NIL) p = pr;
+            else if (pr == NIL) p = pl;
+            else if ((dir = compareKeys(k, nodes[p].key)) != 0) p = (dir < 0) ? pl : pr;
+            else if ((q = treeFind(pr, h, k)) != NIL) return q;
+            else p = pl;
+        } while (p != NIL);
+        return NIL;
+    }
+    int32_t rotateLeft(int32_t root, int32_t p) {
+        int32_t r, pp, rl;
+        if (p != NIL && (r = nodes[p].right) != NIL) {
+            if ((rl = nodes[p].right = nodes[r].left) != NIL) nodes[rl].parent = p;
+            if ((pp = nodes[r].parent = nodes[p].parent) == NIL) nodes[root = r].red = false;
+            else if (nodes[pp].left == p) nodes[pp].left = r;
+            else nodes[pp].right = r;
+            nodes[r].left = p;
+            nodes[p].parent = r;
+        }
+        return root;
+    }
+    int32_t rotateRight(int32_t root, int32_t p) {
+        int32_t l, pp, lr;
+        if (p != NIL && (l = nodes[p].left) != NIL) {
+            if ((lr = nodes[p].left = nodes[l].right) != NIL) nodes[lr].parent = p;
+            if ((pp = nodes[l].parent = nodes[p].parent) == NIL) nodes[root = l].red = false;
+            else if (nodes[pp].right == p) nodes[pp].right = l;
+            else nodes[pp].left = l;
+            nodes[l].right = p;
+            nodes[p].parent = l;
+        }
+        return root;
+    }
+    int32_t balanceInsertion(int32_t root, int32_t x) {
+        nodes[x].red = true;
+        for (int32_t xp, xpp, xppl, xppr;;) {
+            if ((xp = nodes[x].parent) == NIL) { nodes[x].red = false; return x; }
+            else if (!nodes[xp].red || (xpp = nodes[xp].parent) == NIL) return root;
+            if (xp == (xppl = nodes[xpp].left)) {
+                if ((xppr = nodes[xpp].right) != NIL && nodes[xppr].red) {
+                    nodes[xppr].red = false; nodes[xp].red = false; nodes[xpp].red = true;
+                    x = xpp;
+                } else {
+                    if (x == nodes[xp].right) {
+                        root = rotateLeft(root, x = xp);
+                        xpp = (xp = nodes[x].parent) == NIL ? NIL : nodes[xp].parent;
+                    }
+                    if (xp != NIL) {
+                        nodes[xp].red = false;
+                        if (xpp != NIL) { nodes[xpp].red = true; root = rotateRight(root, xpp); }
+                    }
+                }
+            } else {
+                if (xppl != NIL && nodes[xppl].red) {
+                    nodes[xppl].red = false; nodes[xp].red = false; nodes[xpp].red = true;
+                    x = xpp;
+                } else {
+                    if (x == nodes[xp].left) {
+                        root = rotateRight(root, x = xp);
+                        xpp = (xp = nodes[x].parent) == NIL ? NIL : nodes[xp].parent;
+                    }
+                    if (xp != NIL) {
+                        nodes[xp].red = false;
+                        if (xpp != NIL) { nodes[xpp].red = true; root = rotateLeft(root, xpp); }
+                    }
+                }
+            }
+        }
+    }
+    void treeify(int32_t self) {                                // TreeNode.treeify(tab)
+        int32_t root = NIL;
+        for (int32_t x = self, next; x != NIL; x = next) {
+            next = nodes[x].next;
+            nodes[x].left = nodes[x].right = NIL;
+            if (root == NIL) { nodes[x].parent = NIL; nodes[x].red = false; root = x; }
+            else {
+                int32_t k = nodes[x].key, h = nodes[x].hash;
+                for (int32_t p = root;;) {
+                    int dir; int32_t ph;
+                    if ((ph = nodes[p].hash) > h) dir = -1;
+                    else if (ph < h) dir = 1;
+                    else if ((dir = compareKeys(k, nodes[p].key)) == 0) dir = -1;   // tieBreakOrder: not reproducible (unmodelled is set)
+                    int32_t xp = p;
+                    if ((p = (dir <= 0) ? nodes[p].left : nodes[p].right) == NIL) {
+                        nodes[x].parent = xp;
+                        if (dir <= 0) nodes[xp].left = x; else nodes[xp].right = x;
+                        root = balanceInsertion(root, x);
+                        break;
+                    }
+                }
+            }
+        }
+        moveRootToFront(root);
+    }
+    void untreeify(int32_t self) {                              // replacementNode keeps the order; the nodes become plain
+        for (int32_t q = self; q != NIL; q = nodes[q].next) {
+            nodes[q].isTree = false; nodes[q].parent = nodes[q].left = nodes[q].right = nodes[q].prev = NIL; nodes[q].red = false;
+        }
+    }
+    // returns the existing node for the key, or NIL after inserting a new TreeNode
+    int32_t putTreeVal(int32_t self, int32_t h, int32_t k, int64_t v) {
+        bool searched = false;
+        int32_t root = (nodes[self].parent != NIL) ? rootOf(self) : self;
+        for (int32_t p = root;;) {
+            int dir; int32_t ph;
+            if ((ph = nodes[p].hash) > h) dir = -1;
+            else if (ph < h) dir = 1;
+            else if (nodes[p].key == k) return p;
+            else if ((dir = compareKeys(k, nodes[p].key)) == 0) {
+                if (!searched) {
+                    int32_t q, ch;
+                    searched = true;
+                    if (((ch = nodes[p].left) != NIL && (q = treeFind(ch, h, k)) != NIL) ||
+                        ((ch = nodes[p].right) != NIL && (q = treeFind(ch, h, k)) != NIL))
+                        return q;
+                }
+                dir = -1;                                       // tieBreakOrder: not reproducible (unmodelled is set)
+            }
+            int32_t xp = p;
+            if ((p = (dir <= 0) ? nodes[p].left : nodes[p].right) == NIL) {
+                int32_t xpn = nodes[xp].next;
+                nodes.push_back(Node{h, k, v, xpn});            // newTreeNode(h, k, v, xpn)
+                int32_t x = (int32_t)nodes.size() - 1;
+                nodes[x].isTree = true;
+                if (dir <= 0) nodes[xp].left = x; else nodes[xp].right = x;
+                nodes[xp].next = x;
+                nodes[x].parent = nodes[x].prev = xp;
+                if (xpn != NIL) nodes[xpn].prev = x;
+                moveRootToFront(balanceInsertion(root, x));
+                return NIL;
+            }
+        }
+    }
+    void split(std::vector<int32_t>& tab, int32_t b, int32_t index, int32_t bit) {   // TreeNode.split
+        int32_t loHead = NIL, loTail = NIL, hiHead = NIL, hiTail = NIL;
+        int lc = 0, hc = 0;
+        for (int32_t e = b, next; e != NIL; e = next) {
+            next = nodes[e].next;
+            nodes[e].next = NIL;
+            if ((nodes[e].hash & bit) == 0) {
+                if ((nodes[e].prev = loTail) == NIL) loHead = e; else nodes[loTail].next = e;
+                loTail = e; ++lc;
+            } else {
+                if ((nodes[e].prev = hiTail) == NIL) hiHead = e; else nodes[hiTail].next = e;
+                hiTail = e; ++hc;
+            }
+        }
+        if (loHead != NIL) {
+            if (lc <= UNTREEIFY_THRESHOLD) { untreeify(loHead); tab[index] = loHead; }
+            else { tab[index] = loHead; if (hiHead != NIL) treeify(loHead); }   // (else is already treeified)
+        }
+        if (hiHead != NIL) {
+            if (hc <= UNTREEIFY_THRESHOLD) { untreeify(hiHead); tab[index + bit] = hiHead; }
+            else { tab[index + bit] = hiHead; if (loHead != NIL) treeify(hiHead); }
+        }
+    }
+    void treeifyBin(int32_t hash) {
+        int32_t n, index, e;
+        if ((n = (int32_t)table.size()) < MIN_TREEIFY_CAPACITY) resize();
+        else if ((e = table[index = (n - 1) & hash]) != NIL) {
+            int32_t hd = NIL, tl = NIL;
+            do {                                                // replacementTreeNode(e, null): same order, prev links added
+                nodes[e].isTree = true; nodes[e].parent = nodes[e].left = nodes[e].right = NIL; nodes[e].red = false;
+                nodes[e].prev = tl;
+                if (tl == NIL) hd = e;
+                tl = e;
+            } while ((e = nodes[e].next) != NIL);
+            table[index] = hd;
+            treeified = true;
+            treeify(hd);
+        }
     }
 
     void resize() {
@@ -143,10 +374,15 @@ struct JHashMap {
         }
         threshold = newThr;
         std::vector<int32_t> newTab(static_cast<size_t>(newCap), -1);
+        std::vector<int32_t> oldTab;
+        oldTab.swap(table);
+        table.swap(newTab);                                     // `table` IS the new table from here on (treeify -> moveRootToFront uses it)
         if (oldCap > 0) {
             for (int32_t j = 0; j < oldCap; j++) {
-                int32_t e = table[j];
+                int32_t e = oldTab[j];
                 if (e < 0) continue;
+                if (nodes[e].next == NIL) { table[nodes[e].hash & (newCap - 1)] = e; continue; }
+                if (nodes[e].isTree) { split(table, e, j, oldCap); continue; }
                 int32_t loHead = -1, loTail = -1, hiHead = -1, hiTail = -1;
                 while (e >= 0) {
                     int32_t nx = nodes[e].next;
@@ -159,21 +395,24 @@ struct JHashMap {
                     }
                     e = nx;
                 }
-                if (loTail >= 0) { nodes[loTail].next = -1; newTab[j] = loHead; }
-                if (hiTail >= 0) { nodes[hiTail].next = -1; newTab[j + oldCap] = hiHead; }
+                if (loTail >= 0) { nodes[loTail].next = -1; table[j] = loHead; }
+                if (hiTail >= 0) { nodes[hiTail].next = -1; table[j + oldCap] = hiHead; }
             }
         }
-        table.swap(newTab);
     }
 
-    int32_t find(int32_t key, int32_t stringHash) const {
+    int32_t find(int32_t key, int32_t stringHash) {             // getNode
         if (table.empty()) return -1;
         int32_t h = spread(stringHash);
-        int32_t e = table[(static_cast<int32_t>(table.size()) - 1) & h];
-        while (e >= 0) {
-            if (nodes[e].key == key) return e;
-            e = nodes[e].next;
-        }
+        int32_t first = table[(static_cast<int32_t>(table.size()) - 1) & h];
+        if (first < 0) return -1;
+        if (nodes[first].hash == h && nodes[first].key == key) return first;
+        int32_t e = nodes[first].next;
+        if (e < 0) return -1;
+        if (nodes[first].isTree) return treeFind(nodes[first].parent != NIL ? rootOf(first) : first, h, key);   // getTreeNode
+        do {
+            if (nodes[e].hash == h && nodes[e].key == key) return e;
+        } while ((e = nodes[e].next) >= 0);
         return -1;
     }
 
@@ -184,25 +423,26 @@ struct JHashMap {
         int32_t n = static_cast<int32_t>(table.size());
         int32_t i = (n - 1) & h;
         if (table[i] < 0) {
-            nodes.push_back({h, key, val, -1});
+            nodes.push_back(Node{h, key, val, -1});
             table[i] = static_cast<int32_t>(nodes.size()) - 1;
         } else {
             int32_t p = table[i];
-            if (nodes[p].key == key) { nodes[p].val = val; return false; }
-            for (int binCount = 0;; ++binCount) {
-                int32_t e = nodes[p].next;
-                if (e < 0) {
-                    nodes.push_back({h, key, val, -1});
-                    nodes[p].next = static_cast<int32_t>(nodes.size()) - 1;
-                    if (binCount >= 8 - 1) {  // TREEIFY_THRESHOLD - 1
-                        if (static_cast<int32_t>(table.size()) < 64) resize();  // treeifyBin
-                        else unmodelled = true;
+            int32_t e = -1;
+            if (nodes[p].hash == h && nodes[p].key == key) e = p;
+            else if (nodes[p].isTree) e = putTreeVal(p, h, key, val);
+            else {
+                for (int binCount = 0;; ++binCount) {
+                    if ((e = nodes[p].next) < 0) {
+                        nodes.push_back(Node{h, key, val, -1});
+                        nodes[p].next = static_cast<int32_t>(nodes.size()) - 1;
+                        if (binCount >= TREEIFY_THRESHOLD - 1) treeifyBin(h);  // -1 for 1st
+                        break;
                     }
-                    break;
+                    if (nodes[e].hash == h && nodes[e].key == key) break;
+                    p = e;
                 }
-                if (nodes[e].key == key) { nodes[e].val = val; return false; }
-                p = e;
             }
+            if (e >= 0) { nodes[e].val = val; return false; }   // existing mapping for key
         }
         if (++size > threshold) resize();
         return true;
@@ -406,7 +646,10 @@ struct Ctx {
     std::vector<uint8_t> storeValid;                // 0 => loadPointIfActive()==null / decrypt error
     int64_t nIds = 0;
     bool frozen = false;
-    std::atomic<bool> unmodelled{false};  // a HashMap treeified somewhere: order not pinned
+    bool decimalIds = false;              // ids are Long.toString(handle): String.compareTo between two ids is computable
+    std::atomic<bool> unmodelled{false};  // a tree bin needed the order of two different ids with EQUAL hashCode and the ids' Strings
+                                          // are not known here (non-decimal ids): iteration order not pinned
+    std::atomic<bool> treeified{false};   // some HashMap turned a bin into a tree (modelled; what the product's kernels detect)
 
     // per-thread "last" fields are returned via out-params instead
 };
@@ -447,9 +690,10 @@ void greedyBuild(Ctx& c, const std::vector<int32_t>& order, const uint64_t* code
     out.clear();
     if (order.empty()) return;
     // PIS:413-420: new HashMap<>(S.staged.size()); put(id, code) in staged order
-    JHashMap idToCode((int32_t)order.size());
+    JHashMap idToCode((int32_t)order.size(), c.decimalIds);
     for (size_t i = 0; i < order.size(); i++) idToCode.put(order[i], c.javaHash[order[i]], (int64_t)i);
     if (idToCode.unmodelled) c.unmodelled = true;
+    if (idToCode.treeified) c.treeified = true;
     struct Ent { int32_t id; int64_t key; int64_t src; };
     std::vector<Ent> ordered;
     ordered.reserve(order.size());
@@ -496,7 +740,7 @@ int collectPartitionOrdered(const Ctx& c, const Partition& p, const uint64_t* qB
 void routeTraverse(Ctx& c, const uint64_t* qCodes, int probes, std::vector<Cand>& out, int& rawSeen, bool* treeified = nullptr) {
     const int W = c.W();
     const int HARD_CAP = std::max(c.maxGlobalCandidates, c.refinementLimit);  // PIS:612-615
-    JHashMap best(std::min(HARD_CAP, 1 << 16));                                // PIS:619
+    JHashMap best(std::min(HARD_CAP, 1 << 16), c.decimalIds);                  // PIS:619
     rawSeen = 0;
     for (int t = 0; t < c.T && best.size < HARD_CAP; t++) {          // PIS:624
         for (int dv = 0; dv < c.D && best.size < HARD_CAP; dv++) {   // PIS:628
@@ -529,7 +773,8 @@ void routeTraverse(Ctx& c, const uint64_t* qCodes, int probes, std::vector<Cand>
         }
     }
     if (best.unmodelled) c.unmodelled = true;
-    if (treeified) *treeified = best.unmodelled;
+    if (best.treeified) c.treeified = true;
+    if (treeified) *treeified = best.treeified;
     out.clear();
     out.reserve(best.size);
     best.forEach([&](int32_t id, int64_t v) { out.push_back({id, v}); });     // PIS:690-693
@@ -666,15 +911,16 @@ void orc_decimal_hashes(int64_t n, int32_t* out) {
 int32_t orc_table_size_for(int32_t c) { return JHashMap::tableSizeFor(c); }
 
 // HashMap iteration order of `n` keys inserted in the given order into new HashMap<>(initialCapacity).
-// Returns 1 if a bin treeified (order unmodelled).
+// Returns flags: bit 0 = a bin was treeified at some point (modelled), bit 1 = unmodelled (String.compareTo between two
+// different keys with equal hashCode was needed and the keys are not decimal ordinals).  decimalKeys: keys are Long.toString(key).
 int orc_hashmap_order(int32_t initialCapacity, int64_t n, const int32_t* keys, const int32_t* hashes,
-                      int32_t* out_keys, int32_t* out_final_cap) {
-    JHashMap mp(initialCapacity);
+                      int32_t* out_keys, int32_t* out_final_cap, int decimalKeys) {
+    JHashMap mp(initialCapacity, decimalKeys != 0);
     for (int64_t i = 0; i < n; i++) mp.put(keys[i], hashes[i], 0);
     int64_t k = 0;
     mp.forEach([&](int32_t key, int64_t) { out_keys[k++] = key; });
     if (out_final_cap) *out_final_cap = (int32_t)mp.table.size();
-    return mp.unmodelled ? 1 : 0;
+    return (mp.treeified ? 1 : 0) | (mp.unmodelled ? 2 : 0);
 }
 
 // PriorityQueue trace: ops[i] >= 0 => add(idx=i, dist=ops[i]); ops[i] == -1 => poll (writes idx to out).
@@ -759,6 +1005,7 @@ void* orc_ctx_create(int T, int D, int m, int lambda, int d, int maxGlobalCandid
 }
 void orc_ctx_destroy(void* p) { delete static_cast<Ctx*>(p); }
 int orc_unmodelled(void* p) { return static_cast<Ctx*>(p)->unmodelled ? 1 : 0; }
+int orc_treeified(void* p) { return static_cast<Ctx*>(p)->treeified ? 1 : 0; }
 
 void orc_set_gfunctions(void* p, const double* alpha, const double* r, const double* omega) {
     Ctx* c = static_cast<Ctx*>(p);
@@ -773,6 +1020,9 @@ void orc_set_id_meta(void* p, int64_t n, const int32_t* javaHash, const uint8_t*
     Ctx* c = static_cast<Ctx*>(p);
     c->nIds = n;
     c->javaHash.resize(n);
+    c->decimalIds = (javaHash == nullptr);
+    c->unmodelled = false;   // new hashCodes: what earlier maps did says nothing about the ones to come
+    c->treeified = false;
     if (javaHash) std::copy(javaHash, javaHash + n, c->javaHash.begin());
     else for (int64_t i = 0; i < n; i++) c->javaHash[i] = java_decimal_hash(i);
     if (deleted) c->deleted.assign(deleted, deleted + n); else c->deleted.clear();
@@ -829,10 +1079,12 @@ void orc_build_index(void* p, int64_t n, const int32_t* order, const uint64_t* c
         Ctx tmp;  // private flag holder to stay race-free
         tmp.blockSize = c->blockSize;
         tmp.javaHash = c->javaHash;
+        tmp.decimalIds = c->decimalIds;
         greedyBuild(tmp, ord, cw.data(), W, c->tables[td]);
-        unm |= tmp.unmodelled ? 1 : 0;
+        unm |= (tmp.unmodelled ? 1 : 0) | (tmp.treeified ? 2 : 0);
     }
-    if (unm) c->unmodelled = true;
+    if (unm & 1) c->unmodelled = true;
+    if (unm & 2) c->treeified = true;
     c->frozen = true;
 }
 // Staged order of the stock pipeline: first MIN_SAMPLE_SIZE-1 ids parked, flushed last.

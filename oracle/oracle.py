@@ -89,14 +89,24 @@ def table_size_for(c: int) -> int:
     return lib().orc_table_size_for(c)
 
 
-def hashmap_order(initial_capacity: int, keys, hashes):
+def hashmap_order_ex(initial_capacity: int, keys, hashes, decimal=False):
+    """Iteration order of `keys` put in that order into new HashMap<>(initial_capacity) — tree bins included.
+    Returns (order, final table length, treeified, unmodelled): treeified = some bin became a red-black tree (modelled);
+    unmodelled = a tree bin needed String.compareTo between two different keys with equal hashCode and the keys are not
+    decimal ordinals (decimal=True: the key IS the number whose decimal string is the id)."""
     keys = _c(keys, np.int32)
     hashes = _c(hashes, np.int32)
     out = np.empty_like(keys)
     cap = C.c_int32(0)
-    unm = lib().orc_hashmap_order(C.c_int32(initial_capacity), C.c_int64(len(keys)), _p(keys), _p(hashes),
-                                  _p(out), C.byref(cap))
-    return out, cap.value, bool(unm)
+    fl = lib().orc_hashmap_order(C.c_int32(initial_capacity), C.c_int64(len(keys)), _p(keys), _p(hashes),
+                                 _p(out), C.byref(cap), C.c_int(1 if decimal else 0))
+    return out, cap.value, bool(fl & 1), bool(fl & 2)
+
+
+def hashmap_order(initial_capacity: int, keys, hashes, decimal=False):
+    """(order, final table length, treeified) — see hashmap_order_ex."""
+    out, cap, tree, _ = hashmap_order_ex(initial_capacity, keys, hashes, decimal)
+    return out, cap, tree
 
 
 def pq_trace(ops):
@@ -208,7 +218,13 @@ class Oracle:
 
     @property
     def unmodelled(self) -> bool:
+        """A tree bin needed the order of two different ids with equal hashCode whose Strings are unknown (non-decimal ids)."""
         return bool(lib().orc_unmodelled(self._h))
+
+    @property
+    def treeified(self) -> bool:
+        """Some HashMap of this context turned a bin into a red-black tree (modelled)."""
+        return bool(lib().orc_treeified(self._h))
 
     def set_gfunctions(self, alpha, r, omega):
         self.alpha = _c(alpha, np.float64).reshape(self.TD, self.m, self.d)
