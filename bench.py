@@ -582,6 +582,54 @@ def main():
     stage_ms = np.array([[evs[i][j].elapsed_time(evs[i][j + 1]) for j in range(4)] for i in range(nprof)])
     st_mean = stage_ms.mean(axis=0)
 
+    # ---------------- encode (north_star: "MFMA utilisation" beside the HBM figure) -------------------------------------------
+    # query side: the exact fp64 VALU kernel (sequential chain per lane = Java's dot, bit-exact by construction); index side
+    # (Setup, n >= 4096 rows per call): MFMA fp32 GEMM pre-filter with the quantise + bit-pack fused into its epilogue + exact
+    # re-check of the pairs it cannot decide.  flops = 2 * rows * d * (T*D*m).
+    encode_stage = None
+    if rank == 0:
+        FP64_VALU_PEAK, F32_MFMA_PEAK = 78.6, 157.3      # TFLOP/s: MI355X fp64 vector (half the fp32 vector rate), fp32 matrix (MI355X_MICROARCH.md)
+        fl_q = 2.0 * Q * d * TD * m
+        enc_ms = float(st_mean[0])
+        nq_e = int(min(n, 1 << 18))
+        base_e = ctx.L.fspann_store_dev_ptr(ctx.handle, None)
+        codes_e = torch.zeros((nq_e, TD, W), dtype=torch.int64, device=dev)
+        bad_e = torch.zeros(nq_e, dtype=torch.int32, device=dev)
+        ctx.set_encode_mode(2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            ctx.encode_dev(nq_e, base_e, F32, codes_e.data_ptr(), 0, bad_e.data_ptr())
+        ctx.sync()
+        e0.record(streams[0])
+        for _ in range(5):
+            ctx.encode_dev(nq_e, base_e, F32, codes_e.data_ptr(), 0, bad_e.data_ptr())
+        e1.record(streams[0])
+        ctx.sync()
+        mf_ms = e0.elapsed_time(e1) / 5
+        rechecked = ctx.last_encode_rechecked()
+        codes_m = codes_e.clone()
+        ctx.set_encode_mode(1)
+        ctx.encode_dev(nq_e, base_e, F32, codes_e.data_ptr(), 0, bad_e.data_ptr())
+        ctx.sync()
+        ctx.set_encode_mode(0)
+        same_codes = bool(torch.equal(codes_m, codes_e))
+        if not same_codes:
+            raise SystemExit("bench: the MFMA coding path and the exact fp64 kernel disagree on the base rows")
+        fl_i = 2.0 * nq_e * d * TD * m
+        encode_stage = dict(
+            query_side=dict(kernel="encode_exact_kernel<float,4> (its workgroups ride inside front_kernel in the default pipeline)", rows=Q,
+                            flops_per_launch=fl_q, ms=round(enc_ms, 5), tflops=round(fl_q / (enc_ms * 1e-3) / 1e12, 3), peak=FP64_VALU_PEAK,
+                            frac=round(fl_q / (enc_ms * 1e-3) / 1e12 / FP64_VALU_PEAK, 5),
+                            bound="fp64 VALU, one sequential dependent chain per lane (Java's dot order): latency of a lone wave, not throughput"),
+            index_side=dict(kernel="encode_mfma_kernel<float> (v_mfma_f32_32x32x2_f32, 64 x 256 block tile, quantise + bit-pack in the epilogue) + encode_fix_kernel",
+                            rows=nq_e, flops_per_call=fl_i, ms_per_call=round(mf_ms, 4), tflops=round(fl_i / (mf_ms * 1e-3) / 1e12, 2), peak=F32_MFMA_PEAK,
+                            frac=round(fl_i / (mf_ms * 1e-3) / 1e12 / F32_MFMA_PEAK, 4), pairs_rechecked_exactly=int(rechecked),
+                            pairs=int(nq_e) * TD * m, codes_equal_exact_kernel=same_codes,
+                            algorithmic_bytes_per_call=nq_e * (d * 4 + TD * W * 8),
+                            note="whole fspann_encode_dev call of 262 144 base rows (clear of the code words, MFMA kernel, re-check kernel), HIP events "
+                                 "on the context's stream; every pair the fp32 result cannot decide is recomputed with the exact fp64 chain"))
+        del codes_e, codes_m, bad_e
+
     # ---------------- extra passes (N = 1; reported beside `value`, never as it) -------------------------------------------
     variants, hbm_proof, cfg4_shape, peak_measured, peak_launch_sized = {}, None, None, None, None
     if extras:
@@ -657,6 +705,7 @@ def main():
                                "(AesGcmCryptoService.java:55-166, EncryptedPoint.java:80-83, KeyManager.java:221-237); host-bound by design")
 
     # one more (untimed) step of batch 0 on context 0: its results are what recall and the CPU baseline are checked on
+    flagged_in_timed_runs = sum(int(c_.unmodelled_queries()) for c_ in ctxs)     # (read + reset: the timed steps leave such queries empty)
     for b_ in bufs:
         b_["nsteps"] = 0
     step_no[0] = 0
@@ -687,8 +736,6 @@ def main():
         ctx.sync()
     out_ids, out_dist = bufs[0]["topk"][0].ids[:Q], bufs[0]["topk"][0].dist[:Q]      # first batch of the first group
     got_ids, got_dist = out_ids.cpu().numpy(), out_dist.cpu().numpy()
-    for c_ in ctxs[1:]:
-        c_.unmodelled_queries()          # (the clones' counters: flagged during the timed region, same rare path)
     if ctx.unmodelled_queries() != 0:
         raise SystemExit("bench: a query stayed unmodelled (equal hashCodes of non-decimal ids inside a treeified bin)")
     if end_to_end is not None:      # same batch through the decrypting pipeline: same answer
@@ -775,6 +822,8 @@ def main():
                               note="two 3.2 GB blocks alternate; events attached to the scan kernel; scan_plus_merge_ms = whole fspann_refine_dev call")
             del cand4
     kname = "refine_stream_kernel<float,float,32,%s>" % ("true" if mode == "store" else "false")
+    if args.pipeline == "front" and not use_tick and mode == "dense" and B <= 256:
+        kname = "refine_stream_fix_kernel<false> (the streaming scan whose workgroups first finish queries the bounded select handed over)"
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, peak_spec=HBM_PEAK_GBS,
                     peak_measured=peak_measured, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     frac_of_measured=round(achieved / peak_measured, 4) if peak_measured else None,
@@ -1001,6 +1050,7 @@ def main():
             "distance_ratio_at_10": ratio if k == 10 else None,
             "recall_at_k": {"k": k, "recall": recall, "distance_ratio": ratio},
             "treeified": {"finished_on_host_while_packing": int(treeified_setup), "finished_on_host_in_checked_batch": int(treeified_batch0),
+                          "flagged_and_left_empty_in_all_timed_and_untimed_runs": int(flagged_in_timed_runs),
                           "note": "queries whose HashMap<String,Long> bestScore treeifies a bin: flagged by the full select (count -1), finished by "
                                   "the library's JDK model on the host (fspann_route_resolve_dev), outside the timed region"},
             "recall_sweep": recall_sweep,
@@ -1012,6 +1062,7 @@ def main():
             "stages_ms": {"encode": round(float(st_mean[0]), 5), "route_select": round(float(st_mean[1]), 5),
                           "stage_candidates": round(float(st_mean[2]), 5), "refine_topk": round(float(st_mean[3]), 5)},
             "roofline": roofline,
+            "encode_stage": encode_stage,
             "route_stage": route_info,
             "variants": variants or None,
             "end_to_end": end_to_end,

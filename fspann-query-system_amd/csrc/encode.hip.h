@@ -244,31 +244,43 @@ __global__ __launch_bounds__(kEncThreads) void encode_exact_kernel(EncodeArgs<TI
 namespace fspann {
 
 typedef float fsp_acc16 __attribute__((ext_vector_type(16)));
-constexpr int kMfmaKT = 32;       // K tile
-constexpr int kMfmaTile = 64;     // block tile: 64 queries x 64 projections, 4 waves as 2 x 2
+typedef float fsp_f4 __attribute__((ext_vector_type(4)));
+constexpr int kMfmaKT = 32;        // K tile
+constexpr int kMfmaTileQ = 64;     // block tile: 64 queries ...
+constexpr int kMfmaTileP = 256;    // ... x 256 projections; wave w owns columns [64 w, 64 w + 64) = 2 x 2 MFMA tiles of 32 x 32
+constexpr int kMfmaTile = kMfmaTileQ;
 
+// One block = 64 vectors x 256 projections (the V tile is read once per 256 projections: with the old 64 x 64 tile every vector
+// row was fetched P / 64 times).  Epilogue: quantise (floor((y + r) / omega), Coding.java:254-255) AND bit-pack (Coding.C,
+// :285-301) in place — the bits of every pair whose fp32 result is provably on the right side of its bucket edges are OR-ed
+// straight into the (pre-zeroed) code words, one ballot per bit plane; the other pairs go to the fix list and encode_fix_kernel
+// ORs THEIR bits after the exact fp64 chain.  No int32 H round trip through HBM, no pack kernel (hashes != null: H is written too).
 template <typename TIn>
-__global__ __launch_bounds__(256) void encode_mfma_kernel(
+__global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
     const TIn* __restrict__ q, int64_t nq, int d, const float* __restrict__ alphaT32 /*[d][P]*/,
-    const double* __restrict__ r, const double* __restrict__ omega, int P, int32_t* __restrict__ hashes,
-    int32_t* __restrict__ bad, int64_t* __restrict__ fix_list, int64_t fix_cap, unsigned long long* __restrict__ fix_count,
-    double alpha_norm_max) {
-    __shared__ float Vs[kMfmaTile][kMfmaKT + 1];
-    __shared__ float As[kMfmaKT][kMfmaTile];
-    __shared__ double rnorm2[kMfmaTile];
-    __shared__ int badrow[kMfmaTile];
+    const double* __restrict__ r, const double* __restrict__ omega, int P, int m, int lambda, int W, int TD, int32_t* __restrict__ hashes,
+    unsigned long long* __restrict__ codes, int32_t* __restrict__ bad, int64_t* __restrict__ fix_list, int64_t fix_cap,
+    unsigned long long* __restrict__ fix_count, double alpha_norm_max) {
+    __shared__ float Vs[kMfmaTileQ][kMfmaKT + 1];
+    __shared__ __align__(16) float As[kMfmaKT][kMfmaTileP];
+    __shared__ double rnorm2[kMfmaTileQ];
+    __shared__ int badrow[kMfmaTileQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int64_t q0 = static_cast<int64_t>(blockIdx.x) * kMfmaTile;
-    const int p0 = blockIdx.y * kMfmaTile;
-    if (tid < kMfmaTile) { rnorm2[tid] = 0.0; badrow[tid] = 0; }
-    fsp_acc16 acc;
+    const int64_t q0 = static_cast<int64_t>(blockIdx.x) * kMfmaTileQ;
+    const int p0 = blockIdx.y * kMfmaTileP;
+    if (tid < kMfmaTileQ) { rnorm2[tid] = 0.0; badrow[tid] = 0; }
+    fsp_acc16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0.0f;
     double nrm[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) nrm[i] = 0.0;
     __syncthreads();
+    const bool a_vec = ((P & 3) == 0);
 
     for (int k0 = 0; k0 < d; k0 += kMfmaKT) {
         // V tile: 64 rows x 32 k; thread t covers column t&31 of rows (t>>5) + 8 i
@@ -284,21 +296,31 @@ __global__ __launch_bounds__(256) void encode_mfma_kernel(
             Vs[row][col] = static_cast<float>(v);
             nrm[i] += v * v;
         }
-        // A tile: 32 k x 64 projections (coalesced rows of alphaT32)
+        // A tile: 32 k x 256 projections (coalesced 16-byte pieces of alphaT32's rows)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int e = tid + i * 256;
-            const int kk = e >> 6, pc = e & 63;
-            float a = 0.0f;
-            if (k0 + kk < d && p0 + pc < P) a = alphaT32[static_cast<int64_t>(k0 + kk) * P + p0 + pc];
-            As[kk][pc] = a;
+            const int e = (tid + i * 256) * 4;
+            const int kk = e >> 8, pc = e & 255;
+            fsp_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (k0 + kk < d) {
+                const float* src = alphaT32 + static_cast<int64_t>(k0 + kk) * P + p0 + pc;
+                if (a_vec && p0 + pc + 3 < P) a = *reinterpret_cast<const fsp_f4*>(src);
+                else {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (p0 + pc + u < P) a[u] = src[u];
+                }
+            }
+            *reinterpret_cast<fsp_f4*>(&As[kk][pc]) = a;
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < kMfmaKT; kk += 2) {
-            const float a = Vs[wm * 32 + (lane & 31)][kk + (lane >> 5)];
-            const float b = As[kk + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            const float a0 = Vs[(lane & 31)][kk + (lane >> 5)], a1 = Vs[32 + (lane & 31)][kk + (lane >> 5)];
+            const float b0 = As[kk + (lane >> 5)][wave * 64 + (lane & 31)], b1 = As[kk + (lane >> 5)][wave * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -310,42 +332,86 @@ __global__ __launch_bounds__(256) void encode_mfma_kernel(
         if ((tid & 31) == 0) rnorm2[(tid >> 5) + 8 * i] = s;
     }
     __syncthreads();
-    if (bad && blockIdx.y == 0 && tid < kMfmaTile && q0 + tid < nq) bad[q0 + tid] = badrow[tid];
+    if (bad && blockIdx.y == 0 && tid < kMfmaTileQ && q0 + tid < nq) bad[q0 + tid] = badrow[tid];
 
     // per-row guard band (y units): gamma * ||v||_2 + f32-underflow floor
     const double gamma = 1.01 * static_cast<double>(d + 4) * 5.9604644775390625e-08 * alpha_norm_max;  // 2^-24
-    if (tid < kMfmaTile) rnorm2[tid] = gamma * sqrt(rnorm2[tid]) * 1.0000001 + static_cast<double>(d) * 1.2e-38;
+    if (tid < kMfmaTileQ) rnorm2[tid] = gamma * sqrt(rnorm2[tid]) * 1.0000001 + static_cast<double>(d) * 1.2e-38;
     __syncthreads();
-    const int col = wn * 32 + (lane & 31);
-    const int p = p0 + col;
-    const double rr = (p < P) ? r[p] : 0.0, ww = (p < P) ? omega[p] : 1.0;
+    const int half = lane >> 5, c32 = lane & 31;
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-        const int row = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        const int64_t qi = q0 + row;
-        if (qi >= nq || p >= P) continue;
-        const double y = static_cast<double>(acc[reg]);
-        const double band = rnorm2[row];
-        const double fl = floor((y + rr) / ww);
-        // bucket edges in y units; safe iff [y - band, y + band] lies strictly inside (edge_lo, edge_hi)
-        // with a margin for the fp64 roundings of the edges and of the reference's own (y + r)/omega
-        const double e_lo = fl * ww - rr, e_hi = (fl + 1.0) * ww - rr;
-        const double mg = 8.9e-16 * (fabs(fl * ww) + fabs(ww) + fabs(rr) + fabs(y));
-        const bool safe = (y - band > e_lo + mg) && (y + band < e_hi - mg) && (fabs(fl) < 2147483000.0) && !badrow[row];
-        hashes[qi * P + p] = java_d2i(fl);
-        if (!safe) {
-            const unsigned long long pos = atomicAdd(fix_count, 1ull);
-            if (pos < static_cast<unsigned long long>(fix_cap)) fix_list[pos] = qi * P + p;
+    for (int ct = 0; ct < 2; ct++) {
+        const int pb = p0 + wave * 64 + ct * 32;            // first projection of this 32-column tile (wave-uniform)
+        const int p = pb + c32;
+        const double rr = (p < P) ? r[p] : 0.0, ww = (p < P) ? omega[p] : 1.0;
+        // bucket guess through the reciprocal (a fp64 divide per pair was as long as the block's whole MFMA phase): ANY guess is
+        // fine, because a pair is accepted only when its error interval lies strictly inside the guessed bucket's own edges
+        const double iw = 1.0 / ww;
+        // the (t,d) tables whose projections fall into this tile: lane (half, seg) packs the bits of table td_first + seg for row-half `half`
+        const int td_first = pb / m;
+        const int td_last = min(P - 1, pb + 31) / m;
+        const int nseg = (pb < P) ? td_last - td_first + 1 : 0;
+        const int my_td = td_first + c32;
+        const bool seg_on = c32 < nseg;
+        const int c_lo = seg_on ? max(0, my_td * m - pb) : 0;
+        const int c_hi = seg_on ? min(min(31, P - 1 - pb), my_td * m + m - 1 - pb) : -1;
+        const int flen = c_hi - c_lo + 1;
+        const int j_lo = pb + c_lo - my_td * m;
+        const unsigned fmask = (flen >= 32) ? 0xFFFFFFFFu : ((1u << max(flen, 0)) - 1u);
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                const int64_t qi = q0 + row;
+                const bool live = (qi < nq) && (p < P);
+                const double y = static_cast<double>(acc[rt][ct][reg]);
+                const double band = rnorm2[row];
+                const double fl = floor((y + rr) * iw);
+                // bucket edges in y units; safe iff [y - band, y + band] lies strictly inside (edge_lo, edge_hi)
+                // with a margin for the fp64 roundings of the edges and of the reference's own (y + r)/omega
+                const double e_lo = fl * ww - rr, e_hi = (fl + 1.0) * ww - rr;
+                const double mg = 8.9e-16 * (fabs(fl * ww) + fabs(ww) + fabs(rr) + fabs(y));
+                const bool safe = live && (y - band > e_lo + mg) && (y + band < e_hi - mg) && (fabs(fl) < 2147483000.0) && !badrow[row];
+                const int32_t h = java_d2i(fl);
+                if (live && hashes) hashes[qi * P + p] = h;
+                if (live && !safe) {
+                    const unsigned long long pos = atomicAdd(fix_count, 1ull);
+                    if (pos < static_cast<unsigned long long>(fix_cap)) fix_list[pos] = qi * P + p;
+                }
+                // Coding.C: bit pos = (lambda-1-i)*m + j  <-  bit i of (h_j ^ 0x80000000); one ballot per plane, low half = the
+                // 32 columns of row `row` (half 0), high half = those of row + 4 (half 1)
+                const uint32_t hj = static_cast<uint32_t>(h) ^ 0x80000000u;
+                unsigned long long w0 = 0, w1 = 0, w2 = 0;
+                for (int i = 0; i < lambda; i++) {                            // uniform trip count: every lane takes part in the ballot
+                    const unsigned long long bm = __ballot(safe && ((hj >> (i & 31)) & 1u));
+                    if (flen > 0) {
+                        const unsigned long long field = (bm >> (half * 32 + c_lo)) & fmask;
+                        const int bp = (lambda - 1 - i) * m + j_lo;
+                        const int wd = bp >> 6, off = bp & 63;
+                        const unsigned long long lo = field << off;
+                        const unsigned long long hi = (off + flen > 64) ? (field >> (64 - off)) : 0ull;
+                        if (wd == 0) { w0 |= lo; w1 |= hi; } else if (wd == 1) { w1 |= lo; w2 |= hi; } else { w2 |= lo; }
+                    }
+                }
+                if (flen > 0 && qi < nq) {
+                    unsigned long long* cw = codes + (qi * TD + my_td) * W;
+                    if (w0) atomicOr(cw, w0);
+                    if (W > 1 && w1) atomicOr(cw + 1, w1);
+                    if (W > 2 && w2) atomicOr(cw + 2, w2);
+                }
+            }
         }
     }
 }
 
-// exact re-computation of the flagged (query, projection) pairs: one lane per pair, the reference's chain.
+// exact re-computation of the flagged (query, projection) pairs: one lane per pair, the reference's chain; the pair's code
+// bits are OR-ed into the code words (the MFMA epilogue left them clear).
 template <typename TIn>
 __global__ __launch_bounds__(256) void encode_fix_kernel(const TIn* __restrict__ q, int d, const double* __restrict__ alphaT,
-                                                         const double* __restrict__ r, const double* __restrict__ omega, int P,
+                                                         const double* __restrict__ r, const double* __restrict__ omega, int P, int m, int lambda, int W, int TD,
                                                          const int64_t* __restrict__ fix_list, const unsigned long long* __restrict__ fix_count,
-                                                         int64_t fix_cap, int32_t* __restrict__ hashes) {
+                                                         int64_t fix_cap, int32_t* __restrict__ hashes, unsigned long long* __restrict__ codes) {
     const unsigned long long n = min(*fix_count, static_cast<unsigned long long>(fix_cap));
     for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
          i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
@@ -359,28 +425,17 @@ __global__ __launch_bounds__(256) void encode_fix_kernel(const TIn* __restrict__
             acc = acc + prod;
         }
         const double y = acc + r[p];
-        hashes[e] = java_d2i(floor(y / omega[p]));
+        const int32_t h = java_d2i(floor(y / omega[p]));
+        if (hashes) hashes[e] = h;
+        const uint32_t hj = static_cast<uint32_t>(h) ^ 0x80000000u;
+        const int td = p / m, j = p - td * m;
+        unsigned long long* cw = codes + (qi * TD + td) * W;
+        for (int b = 0; b < lambda; b++)
+            if ((hj >> (b & 31)) & 1u) {
+                const int pos = (lambda - 1 - b) * m + j;
+                atomicOr(cw + (pos >> 6), 1ull << (pos & 63));
+            }
     }
-}
-
-// Coding.C from the int32 hashes: one thread per code word.
-__global__ __launch_bounds__(256) void encode_pack_kernel(const int32_t* __restrict__ hashes, int64_t nq, int TD, int m, int lambda,
-                                                          int W, uint64_t* __restrict__ codes) {
-    const int64_t wi = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (wi >= nq * TD * W) return;
-    const int64_t qt = wi / W;
-    const int w = static_cast<int>(wi - qt * W);
-    const int32_t* H = hashes + qt * m;
-    const int bitsTotal = m * lambda;
-    uint64_t word = 0;
-    const int pos0 = w * 64, pos1 = min(bitsTotal, pos0 + 64);
-    int plane = pos0 / m, j = pos0 - plane * m;
-    for (int pos = pos0; pos < pos1; pos++) {
-        const uint32_t hj = static_cast<uint32_t>(H[j]) ^ 0x80000000u;
-        word |= static_cast<uint64_t>((hj >> ((lambda - 1 - plane) & 31)) & 1u) << (pos - pos0);
-        if (++j == m) { j = 0; plane++; }
-    }
-    codes[wi] = word;
 }
 
 }  // namespace fspann

@@ -238,23 +238,20 @@ template <typename TIn>
 int launch_encode_mfma(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_dev, int32_t* hashes_dev, int32_t* bad_dev) {
     const int P = c->P_total, d = c->cfg.dim;
     const int64_t cap = std::max<int64_t>(65536, nq * P / 16);
-    const size_t hb = hashes_dev ? 0 : static_cast<size_t>(nq) * P * 4;
-    int rc = ensure(c, c->ws_fix, 256 + static_cast<size_t>(cap) * 8 + hb);
+    int rc = ensure(c, c->ws_fix, 256 + static_cast<size_t>(cap) * 8);
     if (rc) return rc;
     unsigned long long* cnt = static_cast<unsigned long long*>(c->ws_fix.p);
     int64_t* list = reinterpret_cast<int64_t*>(static_cast<char*>(c->ws_fix.p) + 256);
-    int32_t* H = hashes_dev ? hashes_dev : reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_fix.p) + 256 + static_cast<size_t>(cap) * 8);
     FSP_HIP(hipMemsetAsync(cnt, 0, 8, c->stream));
-    dim3 grid(static_cast<unsigned>((nq + kMfmaTile - 1) / kMfmaTile), static_cast<unsigned>((P + kMfmaTile - 1) / kMfmaTile));
-    hipLaunchKernelGGL((encode_mfma_kernel<TIn>), grid, dim3(256), 0, c->stream, q_dev, nq, d, c->d_alphaT32, c->d_r, c->d_omega, P, H,
-                       bad_dev, list, cap, cnt, c->alpha_norm_max);
+    // the code words start clear: the MFMA epilogue ORs in the bits of the pairs it can decide, encode_fix_kernel those of the rest
+    FSP_HIP(hipMemsetAsync(codes_dev, 0, static_cast<size_t>(nq) * c->TD * c->W * 8, c->stream));
+    dim3 grid(static_cast<unsigned>((nq + kMfmaTileQ - 1) / kMfmaTileQ), static_cast<unsigned>((P + kMfmaTileP - 1) / kMfmaTileP));
+    unsigned long long* cw = reinterpret_cast<unsigned long long*>(codes_dev);
+    hipLaunchKernelGGL((encode_mfma_kernel<TIn>), grid, dim3(256), 0, c->stream, q_dev, nq, d, c->d_alphaT32, c->d_r, c->d_omega, P, c->cfg.m, c->cfg.lambda,
+                       c->W, c->TD, hashes_dev, cw, bad_dev, list, cap, cnt, c->alpha_norm_max);
     FSP_HIP(hipGetLastError());
     hipLaunchKernelGGL((encode_fix_kernel<TIn>), dim3(static_cast<unsigned>(std::min<int64_t>(1024, (cap + 255) / 256))), dim3(256), 0, c->stream,
-                       q_dev, d, c->d_alphaT, c->d_r, c->d_omega, P, list, cnt, cap, H);
-    FSP_HIP(hipGetLastError());
-    const int64_t nwords = nq * c->TD * c->W;
-    hipLaunchKernelGGL(encode_pack_kernel, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, c->stream, H, nq, c->TD,
-                       c->cfg.m, c->cfg.lambda, c->W, codes_dev);
+                       q_dev, d, c->d_alphaT, c->d_r, c->d_omega, P, c->cfg.m, c->cfg.lambda, c->W, c->TD, list, cnt, cap, hashes_dev, cw);
     FSP_HIP(hipGetLastError());
     c->fix_cap_last = static_cast<unsigned long long>(cap);
     return 1;  // caller enqueues the exact kernel guarded by (count > cap): it only runs if the list overflowed
@@ -267,7 +264,7 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
     const unsigned long long* guard = nullptr;
     unsigned long long guard_cap = 0;
     const bool want_mfma = (c->encode_mode == 2) || (c->encode_mode == 0 && nq >= 4096);
-    if (want_mfma && !proj_dev && c->d_alphaT32) {
+    if (want_mfma && !proj_dev && c->d_alphaT32 && c->W <= 3) {      // (the fused bit-pack epilogue carries three code words: <= 192 bits)
         int rc = launch_encode_mfma<TIn>(c, nq, q_dev, codes_dev, hashes_dev, bad_dev);
         if (rc <= 0) return rc;  // error
         // the list can only overflow when almost every pair sits on a bucket boundary (degenerate omega): the
@@ -1828,6 +1825,7 @@ int fspann_pointstore_set_master_key(fspann_pointstore* ps, const uint8_t* key32
     std::lock_guard<std::mutex> lk(ps->key_mu);
     std::memcpy(ps->master, key32, 32);
     ps->have_master = true;
+    for (auto& k : ps->keys) if (!k.empty()) cleanse(k.data(), k.size());
     ps->keys.clear();
     return FSPANN_OK;
 }
@@ -1847,7 +1845,10 @@ int fspann_pointstore_retire(fspann_pointstore* ps, int version) {
         std::lock_guard<std::mutex> lk(ps->key_mu);
         if (static_cast<size_t>(version) >= ps->retired.size()) ps->retired.resize(version + 1, 0);
         ps->retired[version] = 1;
-        if (static_cast<size_t>(version) < ps->keys.size()) ps->keys[version].clear();
+        if (static_cast<size_t>(version) < ps->keys.size() && !ps->keys[version].empty()) {
+            cleanse(ps->keys[version].data(), ps->keys[version].size());
+            ps->keys[version].clear();
+        }
         return FSPANN_OK;
     });
 }
@@ -1869,6 +1870,7 @@ int fspann_pointstore_encrypt(fspann_pointstore* ps, int64_t h0, int64_t cnt, co
 int fspann_pointstore_delete(fspann_pointstore* ps, int64_t h) {
     if (!ps) return fail(FSPANN_E_NULL, "point store is null");
     if (h < 0 || h >= ps->n) return fail(FSPANN_E_ARG, "handle out of range");
+    (void)acquire_record(ps, h);                       // not under a writer's feet
     ps->ver(h)->store(0, std::memory_order_release);
     return FSPANN_OK;
 }
@@ -1878,40 +1880,11 @@ int fspann_pointstore_reencrypt(fspann_pointstore* ps, const int32_t* handles, i
     if (!ps || (cnt > 0 && !handles)) return fail(FSPANN_E_NULL, "point store / handles is null");
     if (cnt < 0 || cnt > (1LL << 26)) return fail(FSPANN_E_ARG, "cnt out of range (at most 2^26 handles per call)");
     return guarded([&]() -> int {
-        CryptoApi* a = crypto_api();
-        const int target = ps->current_version.load();
-        unsigned char tkey[32];
-        if (!ps->key_for(target, tkey)) return fail(FSPANN_E_STATE, "current key version is not derivable");
-        std::atomic<long long> done{0};
-        const int dim = ps->dim, ptlen = 8 * dim;
-        std::vector<unsigned char> ivs(static_cast<size_t>(cnt) * kIvBytes);     // fresh IVs, one RAND_bytes call on this thread
-        if (cnt > 0 && a->RAND_bytes(ivs.data(), static_cast<int>(std::min<size_t>(ivs.size(), 1u << 30))) != 1) return fail(FSPANN_E_DEVICE, "RAND_bytes failed");
-        parallel_blocks(cnt, threads, 256, [&](int, int64_t b, int64_t e) {
-            GcmWorker w(a);
-            if (!w.set_enc_key(target, tkey)) return;
-            std::vector<unsigned char> scratch(kIvBytes + 16 * static_cast<size_t>(dim) + kTagBytes + 64), pt(ptlen), sealed(ptlen + kTagBytes);
-            std::vector<double> row(dim);
-            char aad[96];
-            for (int64_t i = b; i < e; i++) {
-                const int64_t h = handles[i];
-                if (h < 0 || h >= ps->n) continue;
-                int oldv = 0;
-                if (!pointstore_open_one(ps, w, h, scratch, row.data(), &oldv)) continue;     // forward-secure skip
-                if (oldv >= target) continue;                                                 // already upgraded
-                for (int j = 0; j < dim; j++) { uint64_t bits; std::memcpy(&bits, &row[j], 8); bits = bswap64(bits); std::memcpy(pt.data() + 8 * j, &bits, 8); }
-                const unsigned char* iv = ivs.data() + static_cast<size_t>(i) * kIvBytes;
-                const int al = aad_for(aad, sizeof(aad), h, target, dim);
-                if (!w.seal(iv, reinterpret_cast<const unsigned char*>(aad), al, pt.data(), ptlen, sealed.data())) continue;
-                int32_t expect = oldv;
-                if (!ps->ver(h)->compare_exchange_strong(expect, -1, std::memory_order_acq_rel)) continue;   // someone else rewrote it meanwhile
-                unsigned char* r = ps->rec(h);
-                std::memcpy(r + 4, iv, kIvBytes);
-                std::memcpy(r + 4 + kIvBytes, sealed.data(), ptlen + kTagBytes);
-                ps->ver(h)->store(target, std::memory_order_release);
-                done++;
-            }
-        });
-        if (reencrypted) *reencrypted = done.load();
+        long long done = 0;
+        const int rc = pointstore_reencrypt(ps, handles, cnt, threads, &done);
+        if (rc == -1) return fail(FSPANN_E_STATE, "current key version is not derivable");
+        if (rc == -2) return fail(FSPANN_E_DEVICE, "RAND_bytes failed");
+        if (reencrypted) *reencrypted = done;
         return FSPANN_OK;
     });
 }
@@ -1932,8 +1905,8 @@ int fspann_pointstore_get_record(fspann_pointstore* ps, int64_t h, int32_t* vers
     if (h < 0 || h >= ps->n) return fail(FSPANN_E_ARG, "handle out of range");
     const int v = ps->ver(h)->load(std::memory_order_acquire);
     if (version) *version = v;
-    if (iv12) std::memcpy(iv12, ps->rec(h) + 4, kIvBytes);
-    if (ct) std::memcpy(ct, ps->rec(h) + 4 + kIvBytes, 8 * static_cast<size_t>(ps->dim) + kTagBytes);
+    if (iv12) copy_from_shared(iv12, ps->rec(h) + 4, kIvBytes);
+    if (ct) copy_from_shared(ct, ps->rec(h) + 4 + kIvBytes, 8 * static_cast<size_t>(ps->dim) + kTagBytes);
     return FSPANN_OK;
 }
 // Import a record sealed elsewhere (the JVM's EncryptedPoint: keyVersion, iv, ciphertext || tag).
@@ -1941,9 +1914,9 @@ int fspann_pointstore_put_record(fspann_pointstore* ps, int64_t h, int32_t versi
     if (!ps || !iv12 || !ct) return fail(FSPANN_E_NULL, "point store / record is null");
     if (h < 0 || h >= ps->n) return fail(FSPANN_E_ARG, "handle out of range");
     if (version <= 0) return fail(FSPANN_E_ARG, "version <= 0");
-    ps->ver(h)->store(-1, std::memory_order_release);
-    std::memcpy(ps->rec(h) + 4, iv12, kIvBytes);
-    std::memcpy(ps->rec(h) + 4 + kIvBytes, ct, 8 * static_cast<size_t>(ps->dim) + kTagBytes);
+    (void)acquire_record(ps, h);
+    copy_to_shared(ps->rec(h) + 4, iv12, kIvBytes);
+    copy_to_shared(ps->rec(h) + 4 + kIvBytes, ct, 8 * static_cast<size_t>(ps->dim) + kTagBytes);
     ps->ver(h)->store(version, std::memory_order_release);
     return FSPANN_OK;
 }
@@ -2621,7 +2594,7 @@ int build_finish_impl(fspann_ctx* c, const int32_t* order) {
         const size_t kb = static_cast<size_t>(n) * 8, pb = static_cast<size_t>(n) * 4;
         auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
         // scratch: ord, bucket, perm0, 2 x keys, 2 x payload, hist, per-table outputs
-        const size_t need = al(pb) * 3 + al(kb) * 2 + al(pb) * 2 + al(static_cast<size_t>(256) * nblocks * 4) + al(np * 8) * 2 + al(np * W * 8) + al((np + 1) * 8) + al(pb);
+        const size_t need = al(pb) * 3 + al(kb) * 2 + al(pb) * 2 + al(static_cast<size_t>(256) * nblocks * 4) + al(2 * 256 * 4) + al(np * 8) * 2 + al(np * W * 8) + al((np + 1) * 8) + al(pb);
         if ((rc = ensure(c, c->ws_io[3], need))) return rc;
         char* w = static_cast<char*>(c->ws_io[3].p);
         auto take = [&](size_t bytes) { char* q = w; w += al(bytes); return q; };
@@ -2631,6 +2604,9 @@ int build_finish_impl(fspann_ctx* c, const int32_t* order) {
         uint64_t* d_key[2] = {reinterpret_cast<uint64_t*>(take(kb)), reinterpret_cast<uint64_t*>(take(kb))};
         uint32_t* d_pay[2] = {reinterpret_cast<uint32_t*>(take(pb)), reinterpret_cast<uint32_t*>(take(pb))};
         uint32_t* d_hist = reinterpret_cast<uint32_t*>(take(static_cast<size_t>(256) * nblocks * 4));
+        uint32_t* d_tot = reinterpret_cast<uint32_t*>(take(2 * 256 * 4));      // digit totals of the radix passes, two arrays in turn
+        int pass_no = 0;
+        FSP_HIP(hipMemsetAsync(d_tot, 0, 2 * 256 * 4, c->stream));
         int64_t* d_min = reinterpret_cast<int64_t*>(take(np * 8));
         int64_t* d_max = reinterpret_cast<int64_t*>(take(np * 8));
         uint64_t* d_repo = reinterpret_cast<uint64_t*>(take(np * W * 8));
@@ -2642,8 +2618,11 @@ int build_finish_impl(fspann_ctx* c, const int32_t* order) {
         // stable LSD radix sort of (key, payload) on the byte digits [p_lo, p_hi]; returns the buffer index holding the result
         auto radix = [&](int cur, int p_lo, int p_hi) -> int {
             for (int p = p_lo; p <= p_hi; p++) {
-                hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(kRsThreads), 0, c->stream, d_key[cur], n, 8 * p, d_hist, nblocks);
-                hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(256), 0, c->stream, d_hist, nblocks);
+                uint32_t* tcur = d_tot + 256 * (pass_no & 1);
+                uint32_t* tnext = d_tot + 256 * ((pass_no & 1) ^ 1);
+                pass_no++;
+                hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(kRsThreads), 0, c->stream, d_key[cur], n, 8 * p, d_hist, nblocks, tcur);
+                hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(256), 0, c->stream, d_hist, nblocks, tcur, tnext);
                 hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(kRsThreads), 0, c->stream, d_key[cur], d_pay[cur], n, 8 * p, d_hist, nblocks,
                                    d_key[cur ^ 1], d_pay[cur ^ 1]);
                 cur ^= 1;

@@ -198,6 +198,16 @@ def test_config3_gist1m_shape_full_size(pkg, oracle):
     assert info["lazy"]
 
 
+def test_config4_shape_at_1m_against_the_oracle(pkg, oracle):
+    """BASELINE config #4's routing and refine SHAPE (32 tables x 64-bit codes, d = 768, B = 1024: the bounded select's 2 048-entry
+    class, four 256-row chunks + merge) at N = 1 M, where the oracle still finishes: its own index (tables 0, 16, 31 compared), then
+    fspann_search_store_dev, the staged full select with counters and the dense chunked refine against oracle.search on 256 queries —
+    so config #4's Route is pinned to the restatement, not only to the other HIP select (the 10 M run below checks properties)."""
+    n = int(os.environ.get("FSPANN_TEST_CFG4S_N", "1000000"))
+    info = _full_parity(pkg, oracle, n=n, d=768, T=32, m=32, B=1024, nq=256, seed=4, all_tables=False)
+    assert info["lazy"], "fspann_search_store_dev did not take the bounded select at config #4's shape"
+
+
 def test_config4_bert10m_shape_properties(pkg, oracle):
     """BASELINE config #4 (10 M x 768, 32 tables x 64 bits, B = 1024): size-independent properties at full N."""
     import torch
