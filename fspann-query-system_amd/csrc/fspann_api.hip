@@ -307,6 +307,8 @@ struct RoutePlan {
     int threads;
     int64_t g_sort_stride;
     // bounded select (route_lazy.hip.h)
+    int lds_sort_words;
+    bool long_lists;
     int lazy, lazy_cap, lz_ht_size, lz_grid, lz_entries;
     size_t lz_lds_bytes, small_bytes;
 };
@@ -346,9 +348,20 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
         while (pl.sort_cap < full_sort && ((arena(pl.sort_cap * 2) + 255) & ~size_t(255)) + small <= budget) pl.sort_cap *= 2;
         pl.arena_bytes = (arena(pl.sort_cap) + 255) & ~size_t(255);
     }
-    pl.lds_bytes = pl.lds_mode ? pl.arena_bytes + small : small;
+    // long lists are ordered score group by score group in LDS (route.hip.h, phase C): in LDS mode the hash table's space is
+    // reused, in global mode 64 KB behind the small arrays are reserved for it
+    pl.lds_sort_words = 0;
+    pl.long_lists = std::min<int64_t>(limit, pl.maxcand) > kRankSortMax - 128;
+    if (!pl.lds_mode && pl.long_lists && small + 65536 + 64 <= budget) pl.lds_sort_words = 16384;
+    pl.lds_bytes = pl.lds_mode ? pl.arena_bytes + small : small + static_cast<size_t>(pl.lds_sort_words) * 4 + 16;
     const int per_cu = std::max<int>(1, static_cast<int>(static_cast<size_t>(c->lds_limit) / (pl.lds_bytes + 512)));
-    pl.grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * std::min(per_cu, 4)));
+    int wgs_per_cu = std::min(per_cu, 4);
+    if (!pl.lds_mode) {
+        // every workgroup owns an arena slice (hash table, tuples) in global memory that it hits at random: keep the slices of
+        // all resident workgroups inside the 256 MiB Infinity Cache (1024 workgroups x 470 KB at SIFT_P10_HIGH thrashed HBM)
+        wgs_per_cu = (pl.arena_bytes * static_cast<size_t>(c->num_cus) * 2 <= (size_t(128) << 20)) ? std::min(wgs_per_cu, 2) : 1;
+    }
+    pl.grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * wgs_per_cu));
     pl.g_sort_stride = (pl.sort_cap < full_sort) ? full_sort : 0;
     // ---- bounded select: legal when the first `limit` entries do not depend on how many ids exist ----------------
     pl.lazy = 0;
@@ -575,6 +588,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_tick_refine = std::min(4, std::max(1, env_int("FSPANN_TICK_REFINE", 1)));
         c->knob_gpu_cut = env_int("FSPANN_GPU_CUT", 1) != 0;
         c->knob_tick_fuse = env_int("FSPANN_TICK_FUSE", 1) != 0;
+        c->knob_wave_sort = env_int("FSPANN_ROUTE_WAVE_SORT", 1);      // 1: per-wave group sorts, 0: whole-workgroup group sorts, -1: general sort only
         c->knob_tick_front = std::min(100, std::max(0, env_int("FSPANN_TICK_FRONT", 100)));
     }
     c->h_min.resize(c->TD); c->h_max.resize(c->TD); c->h_off.resize(c->TD); c->h_rep.resize(c->TD); c->h_ids.resize(c->TD);
@@ -1074,7 +1088,8 @@ int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int prob
     // global arenas of the full select: per-workgroup scratch when it does not fit LDS, the sort buffer of long lists
     const size_t ar_g = pl.lds_mode ? 0 : static_cast<size_t>(pl.grid) * pl.arena_bytes;
     const size_t so_g = static_cast<size_t>(pl.grid) * pl.g_sort_stride * 8;
-    if (ar_g + so_g && (rc = ensure(c, c->ws_route, ar_g + so_g + 512))) return rc;
+    const size_t su_g = pl.long_lists ? static_cast<size_t>(pl.grid) * static_cast<size_t>(pl.maxcand) * 4 : 0;     // sub-keys grouped by score
+    if (ar_g + so_g + su_g && (rc = ensure(c, c->ws_route, ar_g + so_g + su_g + 1024))) return rc;
     RouteParams p{};
     p.codes = codes_dev; p.tables = c->d_tables; p.recs = c->d_recs; p.rec_words = c->rec_words; p.ids = c->d_ids;
     p.dir = c->knob_probe_dir ? c->d_dir : nullptr; p.dir_bits = c->dir_bits;
@@ -1087,6 +1102,11 @@ int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int prob
     p.g_sort_stride = pl.g_sort_stride;
     p.g_scratch = ar_g ? static_cast<unsigned char*>(c->ws_route.p) + ((so_g + 255) & ~size_t(255)) : nullptr;
     p.g_stride = static_cast<int64_t>(pl.arena_bytes);
+    p.g_sub = su_g ? reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->ws_route.p) + ((so_g + 255) & ~size_t(255)) + ((ar_g + 255) & ~size_t(255))) : nullptr;
+    p.g_sub_stride = pl.maxcand;
+    p.lds_sort_words = pl.lds_sort_words;
+    p.wave_sort = c->knob_wave_sort > 0 ? 1 : 0;
+    if (c->knob_wave_sort < 0) p.g_sub = nullptr;
     p.dbg = c->dbg_route;
     p.unmodelled = c->d_unmodelled;
     p.decimal_ids = c->decimal_ids ? 1 : 0;
@@ -1492,6 +1512,7 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
         pX.g_scratch = static_cast<unsigned char*>(c->ws_tickfix.p) + ((so + 255) & ~size_t(255));
         pX.g_stride = static_cast<int64_t>(arena);
         pX.qcount = nullptr; pX.qlist = nullptr;
+        pX.g_sub = nullptr; pX.lds_sort_words = 0;      // (limit <= 512 here: the long-list ordering is never reached)
     }
 
     // ---- can the three roles share one kernel?

@@ -97,6 +97,7 @@ struct fspann_ctx {
     int knob_refine_stream = -1;     // FSPANN_REFINE_STREAM: workgroups per CU of the streaming refinement scan (-1: 4 dense / 3 gather, 0: one workgroup per query)
     int knob_tick_refine = 1;        // FSPANN_TICK_REFINE: refine workgroups per CU inside a tick (each streams several queries)
     int knob_gpu_cut = 1;            // FSPANN_GPU_CUT=0: fspann_build_index cuts the partitions on host threads (std::sort) instead of the GPU radix sort
+    int knob_wave_sort = 1;          // FSPANN_ROUTE_WAVE_SORT=0: long lists' groups are sorted by the whole workgroup one by one (dev A/B)
     int knob_tick_fuse = 1;          // FSPANN_TICK_FUSE=0: fspann_tick_dev always uses the stand-alone kernels
     int knob_tick_front = 100;       // FSPANN_TICK_FRONT: percent of a tick's Route workgroups that head the grid
     int last_tick_fused = 0;

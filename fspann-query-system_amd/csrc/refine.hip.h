@@ -483,11 +483,15 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         // here: unit == query).  PENDING = handed over by the bounded select: finish its Route with the full select first —
         // rare, so the stream simply starts again afterwards (the tiles requested above are dropped: nothing of them is live
         // across the full select, which needs the registers).
+        // (the counts through the CONSTANT address space: scalar loads, which do not queue behind the tile loads just issued — as
+        // vector loads they waited for both tiles; the Route launch that wrote them finished before this kernel started)
+        typedef const int32_t __attribute__((address_space(4)))* const_cnt_t;
+        const const_cnt_t cc = (const_cnt_t)a.cand_count;
         bool any = false;
-        for (int64_t u = wg; u < nunits; u += nwg) any = any || (a.cand_count[u] == -2 /* kRoutePending */);
+        for (int64_t u = wg; u < nunits; u += nwg) any = any || (cc[u] == -2 /* kRoutePending */);
         if (any) {
             for (int64_t u = wg; u < nunits; u += nwg)
-                if (a.cand_count[u] == -2) fix(u);
+                if (cc[u] == -2) fix(u);
             iu = wg; it = 0;
             ibase = unit_base(iu);
             load_sources(iu);

@@ -60,6 +60,10 @@ struct RouteParams {
     int64_t g_stride;
     uint64_t* g_sort;              // global sort fallback (per block g_sort_stride u64), may be null
     int64_t g_sort_stride;
+    uint32_t* g_sub;               // long lists: (bucket | seq) sub-keys grouped by score (per block g_sub_stride u32), may be null
+    int64_t g_sub_stride;
+    int lds_sort_words;            // !kLds: u32 words of LDS behind the small arrays for sorting one score group (kLds: the hash table's)
+    int wave_sort;                 // 1: groups are sorted by single waves on their own LDS slices (0: by the whole workgroup, one by one)
     int64_t out_cap;
     int32_t* out_ids;
     int32_t* out_score;
@@ -120,6 +124,40 @@ __device__ __forceinline__ void bitonic_sort_u64(PtrT sb, int n2, int tid, int n
                 }
             }
             __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ void bitonic_sort_u32(uint32_t* sb, int n2, int tid, int nthreads) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = sb[i], b = sb[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { sb[i] = b; sb[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// the same network run by ONE wave on its own LDS slice: no workgroup barrier anywhere (LDS operations of a wave complete in order)
+__device__ __forceinline__ void bitonic_sort_u32_wave(uint32_t* sb, int n2, int lane) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < n2; i += 64) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = sb[i], b = sb[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { sb[i] = b; sb[ixj] = a; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -754,6 +792,126 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 if (i < nsel && part == 0 && rank < nout) {
                     prm.out_ids[qi * prm.out_cap + rank] = tup[static_cast<uint32_t>(key) & kSeqMask];
                     if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = static_cast<int32_t>(key >> (kBucketBits + kSeqBits));
+                }
+            }
+        } else if (prm.g_sub && capbits + prm.seq_bits <= 32 && prm.nbins <= 512 &&
+                   (kLds ? prm.ht_size : prm.lds_sort_words) >= 4096) {
+            // ---- long lists (the reference's shipped profiles: 6-28 k entries): the order key is score | bin | first seq.  There are
+            // at most `bits + 1` scores and the bins are spread evenly, so the list is cut into GROUPS by (score, top bits of the bin)
+            // — a histogram, a prefix sum and ONE scatter pass of 32-bit sub-keys (bin | seq) — and every group (tens to hundreds of
+            // entries) is sorted by ONE WAVE on its own LDS slice, the workgroup's waves taking groups off a counter: no workgroup
+            // barrier inside the sort.  (A bitonic sort of the whole list in global memory — the general fall-back below — was 76 % of
+            // the full select at SIFT_P4_FAST and 68 % at SIFT_P10_HIGH, tools/route_full_stamps.py.)
+            uint32_t* gsort = kLds ? ht : reinterpret_cast<uint32_t*>(sm + ((so + static_cast<size_t>(TD) * 4 + 15) & ~size_t(15)));
+            const int gcap_all = kLds ? prm.ht_size : prm.lds_sort_words;
+            int gb = 0;                                      // top bits of the bin that join the score in the group number
+            while (gb < 5 && gb < capbits && (prm.nbins << (gb + 1)) <= 1024) gb++;
+            const int ngrp = prm.nbins << gb;
+            int32_t* cursor = reinterpret_cast<int32_t*>(gsort) + (gcap_all - 1024);      // [ngrp <= 1024] running output position per group
+            const int nwv = nthreads >> 6;
+            int wcap = 64;                                   // entries one wave can sort in its slice (a power of two)
+            while (wcap * 2 * nwv <= gcap_all - 1024) wcap <<= 1;
+            if (!prm.wave_sort) wcap = 0;
+            uint32_t* gsub = prm.g_sub + static_cast<int64_t>(block_id) * prm.g_sub_stride;
+            __syncthreads();                                 // ht, bins: every wave is past their last use
+            for (int i = tid; i < ngrp; i += nthreads) bins[i] = 0;
+            if (tid == 0) s_cut = 0;                         // s_cut: a group did not fit a wave's slice
+            __syncthreads();
+            auto key_at = [&](int i) -> uint64_t { return (i < prm.sort_cap) ? sortbuf[i] : gs[i]; };
+            auto group_of = [&](uint64_t key) -> int {
+                const int sc = static_cast<int>(key >> (kBucketBits + kSeqBits));
+                const uint32_t bucket = (static_cast<uint32_t>(key >> kSeqBits) & ((1u << kBucketBits) - 1u)) >> bshift;
+                return (sc << gb) | static_cast<int>(bucket >> (capbits - gb));
+            };
+            for (int i = tid; i < nsel; i += nthreads) atomicAdd(&bins[group_of(key_at(i))], 1);
+            __syncthreads();
+            if (wave == 0) {                                 // exclusive prefix of the group sizes
+                int carry = 0;
+                for (int g0 = 0; g0 < ngrp; g0 += 64) {
+                    const int g = g0 + lane;
+                    const int v = (g < ngrp) ? bins[g] : 0;
+                    int incl = v;
+                    for (int off = 1; off < 64; off <<= 1) { const int u2 = __shfl_up(incl, off); if (lane >= off) incl += u2; }
+                    if (g < ngrp) cursor[g] = carry + incl - v;
+                    carry += __shfl(incl, 63);
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < nsel; i += nthreads) {     // scatter: group by group (any order inside a group: it is sorted next)
+                const uint64_t key = key_at(i);
+                const uint32_t bucket = (static_cast<uint32_t>(key >> kSeqBits) & ((1u << kBucketBits) - 1u)) >> bshift;
+                const uint32_t sub = (bucket << prm.seq_bits) | (static_cast<uint32_t>(key) & kSeqMask);
+                gsub[atomicAdd(&cursor[group_of(key)], 1)] = sub;
+            }
+            __threadfence_block();
+            __syncthreads();                                 // cursor[g] is now the END of group g; its start = end - bins[g]
+            const uint32_t seqm = (1u << prm.seq_bits) - 1u;
+            uint32_t* slice = gsort + static_cast<size_t>(wave) * wcap;
+            // Every wave on its own: wave w takes the groups w, w + waves, ... (ascending, so it may stop at the first one behind the
+            // limit).  (Groups handed out through an LDS counter — `if (lane == 0) g = atomicAdd(..)` + broadcast inside a loop with
+            // continue / break — hung the GPU: the compiler's structurised loop went on with lane 0 masked off and g = 0 for ever.)
+            const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+            bool any_big = false;
+            for (int g = wave_s; g < ngrp; g += nwv) {
+                const int c = __builtin_amdgcn_readfirstlane(bins[g]);
+                const int g0 = __builtin_amdgcn_readfirstlane(cursor[g]) - c;
+                if (c > 0 && g0 >= nout) break;              // this group and every later one lie behind the limit
+                if (c > wcap) any_big = true;
+                if (c == 0 || c > wcap) continue;
+                int n2 = 1;
+                while (n2 < c) n2 <<= 1;
+                for (int i = lane; i < n2; i += 64) slice[i] = (i < c) ? gsub[g0 + i] : 0xFFFFFFFFu;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (c > 1) bitonic_sort_u32_wave(slice, n2, lane);
+                const int scg = g >> gb;
+                for (int i = lane; i < c; i += 64) {
+                    const int rank = g0 + i;
+                    if (rank < nout) {
+                        prm.out_ids[qi * prm.out_cap + rank] = tup[slice[i] & seqm];
+                        if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = scg;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();             // the slice is reused by this wave's next group
+            }
+            if (any_big && lane == 0) s_cut = 1;
+            __syncthreads();
+            bool too_big = false;
+            if (s_cut) {                                     // groups beyond a wave's slice: the whole workgroup sorts them one by one
+                for (int g = 0; g < ngrp; g++) {             // block-uniform
+                    const int c = bins[g];
+                    if (c <= wcap) continue;
+                    const int g0 = cursor[g] - c;
+                    if (g0 >= nout) break;
+                    int n2 = 1;
+                    while (n2 < c) n2 <<= 1;
+                    if (n2 > gcap_all - 1024) { too_big = true; break; }     // the PADDED group must fit in front of the cursors
+                    for (int i = tid; i < n2; i += nthreads) gsort[i] = (i < c) ? gsub[g0 + i] : 0xFFFFFFFFu;
+                    __syncthreads();
+                    bitonic_sort_u32(gsort, n2, tid, nthreads);
+                    const int scg = g >> gb;
+                    for (int i = tid; i < c; i += nthreads) {
+                        const int rank = g0 + i;
+                        if (rank < nout) {
+                            prm.out_ids[qi * prm.out_cap + rank] = tup[gsort[i] & seqm];
+                            if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = scg;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (too_big) {                                   // rare: redo with the general path (the keys are still where the compaction put them)
+                int n2 = 1;
+                while (n2 < nsel) n2 <<= 1;
+                for (int i = tid; i < min(nsel, prm.sort_cap); i += nthreads) gs[i] = sortbuf[i];
+                for (int i = nsel + tid; i < n2; i += nthreads) gs[i] = ~0ull;
+                __syncthreads();
+                bitonic_sort_u64(gs, n2, tid, nthreads);
+                for (int i = tid; i < nout; i += nthreads) {
+                    const uint64_t key = gs[i];
+                    prm.out_ids[qi * prm.out_cap + i] = tup[static_cast<uint32_t>(key) & kSeqMask];
+                    if (prm.out_score) prm.out_score[qi * prm.out_cap + i] = static_cast<int32_t>(key >> (kBucketBits + kSeqBits));
                 }
             }
         } else {
