@@ -352,7 +352,13 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     // reused, in global mode 64 KB behind the small arrays are reserved for it
     pl.lds_sort_words = 0;
     pl.long_lists = std::min<int64_t>(limit, pl.maxcand) > kRankSortMax - 128;
-    if (!pl.lds_mode && pl.long_lists && small + 65536 + 64 <= budget) pl.lds_sort_words = 16384;
+    if (!pl.lds_mode && pl.long_lists && small + 65536 + 64 <= budget) {
+        // room for every sub-key of the longest possible list + eight wave slices + the cursors when the budget allows (one workgroup
+        // per CU in this mode anyway), 64 KB otherwise (the sub-keys then go through global memory)
+        const size_t words_max = (budget - small - 64) / 4;
+        const size_t want = static_cast<size_t>(pl.maxcand) + 8 * 512 + 1024;
+        pl.lds_sort_words = static_cast<int>(std::min(words_max, std::max<size_t>(16384, want)));
+    }
     pl.lds_bytes = pl.lds_mode ? pl.arena_bytes + small : small + static_cast<size_t>(pl.lds_sort_words) * 4 + 16;
     const int per_cu = std::max<int>(1, static_cast<int>(static_cast<size_t>(c->lds_limit) / (pl.lds_bytes + 512)));
     int wgs_per_cu = std::min(per_cu, 4);

@@ -809,10 +809,14 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             const int ngrp = prm.nbins << gb;
             int32_t* cursor = reinterpret_cast<int32_t*>(gsort) + (gcap_all - 1024);      // [ngrp <= 1024] running output position per group
             const int nwv = nthreads >> 6;
+            // LDS region: [per-wave slices: nwv * wcap][the sub-keys, when they fit][cursors: 1024].  With the sub-keys in LDS a group
+            // costs no global round trip (one per group and wave was most of what was left of the ordering at SIFT_P4_FAST).
             int wcap = 64;                                   // entries one wave can sort in its slice (a power of two)
-            while (wcap * 2 * nwv <= gcap_all - 1024) wcap <<= 1;
+            const bool sub_lds = nwv * 64 + nsel <= gcap_all - 1024;
+            const int room = sub_lds ? gcap_all - 1024 - nsel : gcap_all - 1024;
+            while (wcap * 2 * nwv <= room && wcap < 4096) wcap <<= 1;
             if (!prm.wave_sort) wcap = 0;
-            uint32_t* gsub = prm.g_sub + static_cast<int64_t>(block_id) * prm.g_sub_stride;
+            uint32_t* gsub = sub_lds ? gsort + (gcap_all - 1024 - nsel) : prm.g_sub + static_cast<int64_t>(block_id) * prm.g_sub_stride;
             __syncthreads();                                 // ht, bins: every wave is past their last use
             for (int i = tid; i < ngrp; i += nthreads) bins[i] = 0;
             if (tid == 0) s_cut = 0;                         // s_cut: a group did not fit a wave's slice
@@ -858,17 +862,25 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 if (c > 0 && g0 >= nout) break;              // this group and every later one lie behind the limit
                 if (c > wcap) any_big = true;
                 if (c == 0 || c > wcap) continue;
-                int n2 = 1;
-                while (n2 < c) n2 <<= 1;
-                for (int i = lane; i < n2; i += 64) slice[i] = (i < c) ? gsub[g0 + i] : 0xFFFFFFFFu;
+                // the group's sub-keys are unique (they carry the seq), so an element's place is the number of smaller ones: an
+                // all-pairs count over the slice — broadcast 16-byte reads, independent of each other — instead of a sorting network
+                // whose every stage waits for the LDS (a lone wave: ~100 cycles per stage, 21 stages for 64 elements)
+                const int c4 = (c + 3) & ~3;
+                for (int i = lane; i < c4; i += 64) slice[i] = (i < c) ? gsub[g0 + i] : 0xFFFFFFFFu;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (c > 1) bitonic_sort_u32_wave(slice, n2, lane);
                 const int scg = g >> gb;
+                const uint4* s4 = reinterpret_cast<const uint4*>(slice);
                 for (int i = lane; i < c; i += 64) {
-                    const int rank = g0 + i;
+                    const uint32_t my = slice[i];
+                    int rk = 0;
+                    for (int j = 0; j < c4 / 4; j++) {
+                        const uint4 v = s4[j];
+                        rk += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my);
+                    }
+                    const int rank = g0 + rk;
                     if (rank < nout) {
-                        prm.out_ids[qi * prm.out_cap + rank] = tup[slice[i] & seqm];
+                        prm.out_ids[qi * prm.out_cap + rank] = tup[my & seqm];
                         if (prm.out_score) prm.out_score[qi * prm.out_cap + rank] = scg;
                     }
                 }
@@ -886,7 +898,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                     if (g0 >= nout) break;
                     int n2 = 1;
                     while (n2 < c) n2 <<= 1;
-                    if (n2 > gcap_all - 1024) { too_big = true; break; }     // the PADDED group must fit in front of the cursors
+                    if (n2 > room) { too_big = true; break; }                // the PADDED group must fit in front of the sub-keys / cursors
                     for (int i = tid; i < n2; i += nthreads) gsort[i] = (i < c) ? gsub[g0 + i] : 0xFFFFFFFFu;
                     __syncthreads();
                     bitonic_sort_u32(gsort, n2, tid, nthreads);
