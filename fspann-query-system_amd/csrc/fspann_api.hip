@@ -329,7 +329,11 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     }
     pl.ht_shift = 32 - __builtin_ctz(pl.ht_size);
     pl.nbins = c->bits + 1;
-    pl.threads = c->knob_threads;
+    // threads per workgroup of the full select: 512 for the short lists of the headline shape; a long list (thousands of entries, one
+    // workgroup per CU) is a string of latency-bound passes over the tuples, where 1024 threads simply halve the trips
+    // (1024 queries at SIFT_P10_HIGH: 5.6 -> 4.6 ms, SIFT_P4_FAST: 643 -> 516 us)
+    pl.threads = (c->knob_threads == 1024 || c->knob_threads == 512) ? c->knob_threads
+                 : (std::min<int64_t>(limit, std::min<int64_t>(mt, static_cast<int64_t>(c->hard_cap) - 1 + pl.S)) > kRankSortMax - 128 ? 1024 : 512);
     const int full_sort = next_pow2(std::max(pl.maxcand, 1));
     pl.sort_cap = std::min(full_sort, 1024);
     const size_t TP = static_cast<size_t>(c->TD) * pl.P;
@@ -352,11 +356,12 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     // reused, in global mode 64 KB behind the small arrays are reserved for it
     pl.lds_sort_words = 0;
     pl.long_lists = std::min<int64_t>(limit, pl.maxcand) > kRankSortMax - 128;
-    if (!pl.lds_mode && pl.long_lists && small + 65536 + 64 <= budget) {
+    if (!pl.lds_mode && small + 65536 + 64 <= budget) {
         // room for every sub-key of the longest possible list + eight wave slices + the cursors when the budget allows (one workgroup
         // per CU in this mode anyway), 64 KB otherwise (the sub-keys then go through global memory)
         const size_t words_max = (budget - small - 64) / 4;
-        const size_t want = static_cast<size_t>(pl.maxcand) + 8 * 512 + 1024;
+        size_t want = static_cast<size_t>(pl.maxcand) + 8 * 512 + 1024;
+        if (static_cast<size_t>(pl.ht_size) <= words_max) want = std::max<size_t>(want, pl.ht_size);     // ... and the hash table itself, if it fits (route.hip.h)
         pl.lds_sort_words = static_cast<int>(std::min(words_max, std::max<size_t>(16384, want)));
     }
     pl.lds_bytes = pl.lds_mode ? pl.arena_bytes + small : small + static_cast<size_t>(pl.lds_sort_words) * 4 + 16;
@@ -583,7 +588,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
     {   // tuning / test knobs: read once per context, never on the call path
         auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; };
         c->knob_ht_x4 = env_int("FSPANN_ROUTE_HT_X4", 0) == 1;
-        c->knob_threads = env_int("FSPANN_ROUTE_THREADS", 512) == 1024 ? 1024 : 512;
+        c->knob_threads = env_int("FSPANN_ROUTE_THREADS", 0);       // 0: 512, and 1024 for long lists (the shipped profiles); 512 / 1024 force
         c->knob_lazy_cap = std::max(0, env_int("FSPANN_ROUTE_LAZY_CAP", 0));
         c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
         c->knob_probe_dir = env_int("FSPANN_ROUTE_DIR", 1) != 0;

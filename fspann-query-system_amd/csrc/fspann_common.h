@@ -87,7 +87,7 @@ struct fspann_ctx {
     long long* dbg_route = nullptr;  // per-block phase stamps; only reachable in FSPANN_DEBUG_STAMPS builds (tools/)
     // tuning / test knobs, read from the environment ONCE at fspann_ctx_create (never per call)
     int knob_ht_x4 = 0;              // FSPANN_ROUTE_HT_X4=1: hash load factor <= 0.5 instead of <= 0.8
-    int knob_threads = 512;          // FSPANN_ROUTE_THREADS=1024
+    int knob_threads = 0;            // FSPANN_ROUTE_THREADS: 512 / 1024 force the full select's workgroup size (0: by list length)
     int knob_lazy_cap = 0;           // FSPANN_ROUTE_LAZY_CAP: entries one query may hold in the bounded select (tests)
     int knob_fused_probe = 1;        // FSPANN_ROUTE_FUSED_PROBE=0: separate probe kernel in front of the bounded select
     int knob_refine_dc = 0;          // FSPANN_REFINE_DC: dims per LDS tile of the refinement scan (tools/refine_bench.py)

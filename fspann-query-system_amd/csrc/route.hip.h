@@ -424,6 +424,14 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
     int32_t* stepcnt = reinterpret_cast<int32_t*>(sm + so);      so += static_cast<size_t>(TP) * 4;
     int32_t* nprobe = reinterpret_cast<int32_t*>(sm + so);       so += static_cast<size_t>(TD) * 4;
     int32_t* dupcnt = reinterpret_cast<int32_t*>(sm + so);       // [TD]
+    // Global-arena mode, hash table in LDS: the arrays indexed by tuple number (tup, tscore) are walked in order and can live in
+    // global memory, the hash table is hit at random — when it fits the LDS region behind the small arrays (which phase C then
+    // reuses for the ordering, as it reuses the table's space in LDS mode) it is kept there: global atomics on a 256 KB table per
+    // workgroup were a third of the full select at the reference's larger profiles.
+    if constexpr (!kLds) {
+        if (prm.lds_sort_words >= prm.ht_size && prm.lds_sort_words > 0)
+            ht = reinterpret_cast<uint32_t*>(sm + ((so + static_cast<size_t>(TD) * 4 + 15) & ~size_t(15)));
+    }
 
     __shared__ int s_n, s_raw, s_fill, s_cut, s_star, s_need, s_b1, s_lvl1, s_ndup, s_tree, s_suspect;
 

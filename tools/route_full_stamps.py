@@ -18,7 +18,7 @@ if HAVE_STAMPS:
     L.fspann_debug_route_stamps.argtypes = [C.c_void_p, C.c_void_p]
 dev = torch.device("cuda", 0)
 prof = sys.argv[1] if len(sys.argv) > 1 else "P10"
-T, D, m, P, B, HC = dict(P10=(7, 8, 26, 10, 22000, 28000), P4=(5, 8, 20, 4, 8000, 10000))[prof]
+T, D, m, P, B, HC = dict(P10=(7, 8, 26, 10, 22000, 28000), P4=(5, 8, 20, 4, 8000, 10000), P6=(6, 8, 24, 6, 16000, 20000))[prof]
 n, d, Q = 1_000_000, 128, 1024
 rng = np.random.default_rng(1)
 Cc = rng.standard_normal((4096, d), dtype=np.float32)
