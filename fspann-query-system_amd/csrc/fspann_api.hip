@@ -434,7 +434,7 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     // workgroups per CU of the streaming scan: dense blocks run at 128 registers (4 per CU: a 1024-query batch is exactly one
     // unit per workgroup on 256 CUs), the store gather at 3 per CU; FSPANN_REFINE_STREAM overrides, 0 = per-query scan
     const int stream_wgs = (c->knob_refine_stream >= 0) ? std::min(c->knob_refine_stream, GATHER ? 3 : 4) : (GATHER ? 3 : 4);
-    if constexpr (DC * sizeof(TC) == 128) if (vec && stream_wgs > 0) {
+    if constexpr (DC * sizeof(TC) == 128) if (vec && stream_wgs > 0 && nq * nchunks < (int64_t(1) << 31)) {
         // the scan as a stream: knob_refine_stream workgroups per CU, each walking several (query, chunk) units with the loads
         // of the next two tiles in flight across unit boundaries (refine_stream_run)
         const int64_t units = nq * nchunks;

@@ -109,34 +109,45 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
     RefinePartial* __restrict__ partial = a.partial;
     int32_t* __restrict__ partial_cnt = a.partial_cnt;
     __shared__ uint64_t s_wcut[kRefRows / 64];
-    __shared__ int s_wbase[kRefRows / 64], s_wsurvn[kRefRows / 64];
+    __shared__ int s_wbase[kRefRows / 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- stable rank by (distance bits, candidate position) -------------------------------------
-    // Scratch lives in each wave's OWN (now dead) tile rows, so the per-wave steps need no workgroup barrier:
-    //   wkeys[64]  the wave's keys           wsurv[64]  the wave's survivors (keys <= the chunk-wide cut)
-    uint64_t* wbase_ptr = reinterpret_cast<uint64_t*>(tile + static_cast<size_t>(wave) * 64 * PITCH);
-    uint64_t* wkeys = wbase_ptr;
-    uint64_t* wsurv = wbase_ptr + 64;
-    auto wave_scratch = [&](int w) { return reinterpret_cast<uint64_t*>(tile + static_cast<size_t>(w) * 64 * PITCH); };
+    // Scratch lives in each wave's OWN (now dead) 64 tile rows until the first barrier (other waves may still be reading
+    // theirs): bytes [0, 512) = the wave's 64 keys; afterwards bytes [512, 1536) of region c hold entries [64 c, 64 c + 64)
+    // of the chunk's survivor list (16 bytes each: key, id, candidate position).
+    constexpr size_t kRegion = static_cast<size_t>(64) * PITCH * sizeof(TC);
+    static_assert(kRegion >= 1536 && kRegion % 16 == 0, "a wave's tile rows hold its keys and a quarter of the survivor list");
+    auto wave_scratch = [&](int w) { return reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(tile) + static_cast<size_t>(w) * kRegion); };
+    auto surv = [&](int i) { return reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(tile) + static_cast<size_t>(i >> 6) * kRegion + 512) + (i & 63); };
+    uint64_t* wkeys = wave_scratch(wave);
+    const bool filter = (k <= kRefFilterMaxK);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     wkeys[lane] = key;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int wvalid = __popcll(__ballot(valid));
-    const bool filter = (k <= kRefFilterMaxK);
     if (filter) {
-        // the wave's k-th smallest key bounds the chunk's k-th smallest from above
-        int lrank = 64;
-        if (valid) lrank = rank_among(wkeys, 64, key, lane);
-        const unsigned long long hit = __ballot(valid && lrank == k - 1);
-        uint64_t wc = kInvalidKey;
-        if (hit) wc = __shfl(key, __ffsll(static_cast<long long>(hit)) - 1);
+        // All the cut has to be is an UPPER BOUND of the chunk's k-th smallest key; the survivors are ranked exactly below.
+        // The wave bisects the top word of its keys (finite non-negative doubles: bit 31 clear; an invalid lane never counts):
+        // T = the largest multiple of 2^kCutLow with fewer than k of the wave's top words below it, so at least k keys lie
+        // below (T + 2^kCutLow) << 32.  One vector compare per step, the rest is scalar work — this epilogue is the tail of
+        // the launch, every wave of a SIMD is in it at once and they share one vector pipe (an exact all-pairs rank of the
+        // wave's 64 keys: ~400 vector instructions per wave, 1.5 us of the launch).
+        constexpr int kCutLow = 10;
+        const uint32_t hi = valid ? static_cast<uint32_t>(key >> 32) : 0xFFFFFFFFu;
+        uint32_t T = 0;
+#pragma unroll
+        for (int b = 30; b >= kCutLow; b--) {
+            const uint32_t c = T | (1u << b);
+            T = (__popcll(__ballot(hi < c)) < k) ? c : T;
+        }
+        const uint64_t wc = (wvalid >= k) ? ((static_cast<uint64_t>(T + (1u << kCutLow)) << 32) - 1ull) : kInvalidKey;
         if (lane == 0) s_wcut[wave] = wc;
     }
     if (lane == 0) s_wbase[wave] = wvalid;
-    __syncthreads();   // (1) cuts + valid counts of all waves
+    __syncthreads();   // (1) keys, cuts and valid counts of all waves
     int nvalid = 0;
     uint64_t cutk = kInvalidKey;
 #pragma unroll
@@ -145,33 +156,62 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
         if (filter) cutk = min(cutk, s_wcut[w]);
     }
     const int eff = min(k, nvalid);
-    int rank = kRefRows;
-    if (filter) {
-        // survivors: keys <= the tightest cut (<= k per wave, plus exact ties); each wave keeps its own ordered list
-        const bool sv = valid && key <= cutk;
-        const unsigned long long bm = __ballot(sv);
-        const int ns = __popcll(bm);
-        const int mypos = __popcll(bm & ((1ull << lane) - 1ull));
-        if (sv) wsurv[mypos] = key;
-        if (lane == 0) {
-            if (ns & 1) wsurv[ns] = kInvalidKey;   // pad to an even count for the 16-byte reads
-            s_wsurvn[wave] = ns;
+    // a winner goes to its place in the result (or, when B spans several chunks, in this chunk's partial list)
+    auto emit = [&](const int rank, const uint64_t wkey, const int32_t wid, const int32_t wpos) {
+        if (nchunks == 1) {
+            out_ids[qi * k + rank] = wid;
+            out_dist[qi * k + rank] = __longlong_as_double(static_cast<long long>(wkey));
+        } else {
+            RefinePartial pp;
+            pp.key = wkey;
+            pp.pos = wpos;
+            pp.id = wid;
+            partial[(qi * nchunks + chunk) * k + rank] = pp;
         }
-        __syncthreads();   // (2) survivor lists of all waves
-        if (sv) {
-            rank = 0;
+    };
+    if (filter) {
+        // Survivors = valid keys <= the tightest cut (>= eff of them, typically ~3 k).  Every wave derives the survivor masks
+        // of ALL four waves from the keys in LDS (four loads and ballots — no second exchange of counts), so it knows where
+        // its own survivors go in ONE dense list, in candidate-position order.
+        unsigned long long bm_mine = 0;
+        int mybase = 0, T = 0;
 #pragma unroll
-            for (int w = 0; w < kRefRows / 64; w++) {
-                const int n2 = (s_wsurvn[w] + 1) & ~1;
-                const ulonglong2* l2 = reinterpret_cast<const ulonglong2*>(wave_scratch(w) + 64);
-                // earlier waves hold earlier candidate positions: they win ties; later waves lose them
-                if (w < wave) { for (int j = 0; j < n2 / 2; j++) { const ulonglong2 kk = l2[j]; rank += (kk.x <= key) + (kk.y <= key); } }
-                else if (w > wave) { for (int j = 0; j < n2 / 2; j++) { const ulonglong2 kk = l2[j]; rank += (kk.x < key) + (kk.y < key); } }
-                else rank += rank_among(wave_scratch(w) + 64, n2, key, mypos);
+        for (int w = 0; w < kRefRows / 64; w++) {
+            const uint64_t kw = wave_scratch(w)[lane];
+            const unsigned long long bmw = __ballot(kw <= cutk && kw != kInvalidKey);
+            if (w == wave) { mybase = T; bm_mine = bmw; }
+            T += __popcll(bmw);
+        }
+        if ((bm_mine >> lane) & 1ull) {
+            // (mbcnt = set bits of the mask below this lane: no lane mask to build, hoist and keep alive through the stream)
+            const int at = mybase + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bm_mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bm_mine), 0u)));
+            *surv(at) = make_uint4(static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), static_cast<uint32_t>(my_id), static_cast<uint32_t>(r0 + tid));
+        }
+        __syncthreads();   // (2) the survivor list
+        // Exact rank of survivor i = #{j : (key_j, j) < (key_i, i)}, the T x T pairs spread over the WHOLE workgroup: 2^lgP
+        // consecutive lanes share one i and split the j (T ~ 30: eight lanes per survivor, four pairs each), their partial
+        // counts meet in a few xor-shuffles — a few dozen vector instructions per wave where every wave ranking its own
+        // survivors against all lists took several hundred and a chain of dependent LDS reads.
+        const int lgT = (T <= 1) ? 0 : 32 - __clz(T - 1);     // T <= 2^lgT <= 256
+        const int lgP = min(6, 8 - lgT);
+        const int i = tid >> lgP, part = tid & ((1 << lgP) - 1);
+        int r = 0;
+        if (i < T) {
+            const uint2 mk = *reinterpret_cast<const uint2*>(surv(i));
+            const uint64_t ki = static_cast<uint64_t>(mk.x) | (static_cast<uint64_t>(mk.y) << 32);
+            for (int j = part; j < T; j += (1 << lgP)) {
+                const uint2 o = *reinterpret_cast<const uint2*>(surv(j));
+                const uint64_t kj = static_cast<uint64_t>(o.x) | (static_cast<uint64_t>(o.y) << 32);
+                r += (kj < ki) || (kj == ki && j < i);
             }
         }
+        for (int o = (1 << lgP) >> 1; o >= 1; o >>= 1) r += __shfl_xor(r, o);
+        if (i < T && part == 0 && r < eff) {
+            const uint4 me = *surv(i);
+            emit(r, static_cast<uint64_t>(me.x) | (static_cast<uint64_t>(me.y) << 32), static_cast<int32_t>(me.z), static_cast<int32_t>(me.w));
+        }
     } else if (valid) {
-        rank = 0;
+        int rank = 0;
 #pragma unroll
         for (int w = 0; w < kRefRows / 64; w++) {
             const ulonglong2* l2 = reinterpret_cast<const ulonglong2*>(wave_scratch(w));
@@ -179,13 +219,10 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
             else if (w > wave) { for (int j = 0; j < 32; j++) { const ulonglong2 kk = l2[j]; rank += (kk.x < key) + (kk.y < key); } }
             else rank += rank_among(wkeys, 64, key, lane);
         }
+        if (rank < eff) emit(rank, key, my_id, r0 + tid);
     }
 
     if (nchunks == 1) {
-        if (valid && rank < eff) {
-            out_ids[qi * k + rank] = my_id;
-            out_dist[qi * k + rank] = __longlong_as_double(static_cast<long long>(key));
-        }
         for (int i = eff + tid; i < k; i += kRefRows) {
             out_ids[qi * k + i] = -1;
             out_dist[qi * k + i] = __longlong_as_double(0x7FF0000000000000LL);
@@ -194,18 +231,9 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
             out_count[qi] = eff;
             if (scored) scored[qi] = nvalid;
         }
-    } else {
-        if (valid && rank < eff) {
-            RefinePartial pp;
-            pp.key = key;
-            pp.pos = r0 + tid;
-            pp.id = my_id;
-            partial[(qi * nchunks + chunk) * k + rank] = pp;
-        }
-        if (tid == 0) {
-            partial_cnt[(qi * nchunks + chunk) * 2 + 0] = eff;
-            partial_cnt[(qi * nchunks + chunk) * 2 + 1] = nvalid;
-        }
+    } else if (tid == 0) {
+        partial_cnt[(qi * nchunks + chunk) * 2 + 0] = eff;
+        partial_cnt[(qi * nchunks + chunk) * 2 + 1] = nvalid;
     }
 }
 
@@ -386,6 +414,12 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     const TC* __restrict__ cand = a.cand;
     const int64_t store_n = a.store_n, B = a.B;
     const int d = a.d, nchunks = a.nchunks;
+    // Everything the first tile's addresses need, requested from the kernel-argument segment in ONE round: left alone, the
+    // compiler fetches the block pointer and d in a second round of scalar loads behind the unit arithmetic — a second
+    // memory round trip in front of the first row load, with HBM idle.
+    asm volatile("" :: "s"(cand), "s"(B), "s"(d), "s"(nchunks), "s"(nq));
+    asm volatile("" :: "s"(a.q), "s"(a.cand_ids), "s"(a.cand_count), "s"(a.k), "s"(a.out_ids), "s"(a.out_dist), "s"(a.out_count), "s"(a.scored));
+    asm volatile("" :: "s"(a.partial), "s"(a.partial_cnt), "s"(a.dbg), "s"(a.store_n));
     const int32_t* __restrict__ cand_ids = a.cand_ids;
     TC* tile = reinterpret_cast<TC*>(smem);                                              // [kRefRows][PITCH]
     const int tid = threadIdx.x;
@@ -404,10 +438,18 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     // and the two-tile prefetch is gone (measured: 4.7 us per tile instead of ~1.3).
     int32_t isrc[GATHER ? VPR : 1];                        // gather: store row of each slot for unit iu (clamped into the store)
     int irows = 1;                                         // dense: rows of unit iu that exist in the block
+    // unit -> (query, first row): no division at all for one chunk per query, a 32-bit one otherwise (the launcher keeps
+    // nunits below 2^31) — a 64-bit division is ~100 scalar instructions, and two of them sat in front of the first load
+    auto split_unit = [&](const int64_t uu, int64_t& qi, int& r0) {
+        if (nchunks == 1) { qi = uu; r0 = 0; return; }
+        const uint32_t qq = static_cast<uint32_t>(uu) / static_cast<uint32_t>(nchunks);
+        qi = qq;
+        r0 = static_cast<int>(static_cast<uint32_t>(uu) - qq * static_cast<uint32_t>(nchunks)) * kRefRows;
+    };
     auto load_sources = [&](const int64_t u) {
         const int64_t uu = min(u, nunits - 1);             // past the end: addresses of the last unit (never consumed)
-        const int64_t qi = uu / nchunks;
-        const int r0 = static_cast<int>(uu - qi * nchunks) * kRefRows;
+        int64_t qi; int r0;
+        split_unit(uu, qi, r0);
         const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
         irows = rows_here;
         if constexpr (GATHER) {
@@ -427,8 +469,8 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     auto unit_base = [&](const int64_t u) -> const TC* {
         if constexpr (GATHER) return cand;
         const int64_t uu = min(u, nunits - 1);
-        const int64_t qi = uu / nchunks;
-        const int r0 = static_cast<int>(uu - qi * nchunks) * kRefRows;
+        int64_t qi; int r0;
+        split_unit(uu, qi, r0);
         return cand + (qi * B + r0) * static_cast<int64_t>(d);
     };
     const TC* ibase = unit_base(iu);
@@ -503,14 +545,17 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
 
     // ---- consume side ------------------------------------------------------------------------------------------------
     for (int64_t u = wg; u < nunits; u += nwg) {
-        const int64_t qi = u / nchunks;
-        const int chunk = static_cast<int>(u - qi * nchunks);
-        const int r0 = chunk * kRefRows;
+        int64_t qi; int r0;
+        split_unit(u, qi, r0);
+        const int chunk = r0 / kRefRows;
         // the query row through the CONSTANT address space: uniform loads from it are scalar loads whatever else the
         // enclosing kernel does (see encode_exact_block); the query batch is an input, nothing writes it
         typedef const TQ __attribute__((address_space(4)))* const_row_t;
         const const_row_t qrow = (const_row_t)(a.q + qi * d);
         const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
+#ifdef FSPANN_AB_NOHEAD
+        const int32_t my_id_raw = tid; int cnt_raw = static_cast<int>(B); bool qnf = false; (void)counts_fresh;
+#else
         const int32_t my_id_raw = (tid < rows_here) ? cand_ids[qi * B + r0 + tid] : -1;
         int cnt_raw;
         if (counts_fresh) cnt_raw = __hip_atomic_load(const_cast<int32_t*>(a.cand_count) + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -518,6 +563,7 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         // QSI.java:137-140: a non-finite query gives an empty result.  Every wave looks at the whole query itself.
         bool qnf = false;
         for (int i = lane; i < d; i += 64) qnf = qnf || !__builtin_isfinite(qrow[i]);
+#endif
         // The count, this lane's id and the query check are REQUESTED here but first USED after the last tile: the scan
         // below runs over every row the block holds (tid < rows_here) and the count only decides, in the epilogue, which
         // rows are scored — so no tile waits for this round trip.
@@ -577,7 +623,11 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         uint64_t key = kInvalidKey;
         if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
         RS_STAMP(5);
+#ifdef FSPANN_AB_NOEMIT
+        if (valid && tid < a.k) { a.out_ids[qi * a.k + tid] = my_id; a.out_dist[qi * a.k + tid] = __longlong_as_double(static_cast<long long>(key)); }
+#else
         refine_topk_emit<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, chunk, r0);
+#endif
         RS_STAMP(6);
         __syncthreads();       // every wave has finished reading the other waves' scratch before the tile is written again
         first_unit = false;

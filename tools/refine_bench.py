@@ -4,6 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
+if os.environ.get('AB_LIB'): pkg._native._SO = os.environ['AB_LIB']   # a variant build (dev experiments)
 import os
 Q, B, d, k = 1024, 256, 128, int(os.environ.get('KK', '10'))
 ctx = pkg.FspannContext(pkg.PaperRuntimeConfig(tables=1, divisions=1, m=8, lambda_=2, dim=d, refinement_limit=B), 0)

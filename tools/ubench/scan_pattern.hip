@@ -17,7 +17,7 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #define LD(p) __builtin_nontemporal_load(reinterpret_cast<const u4*>(p))
 
 template <int MODE, int WGS_PER_CU>
-__global__ __launch_bounds__(256, WGS_PER_CU) void pat(const char* __restrict__ x, unsigned* out, int nunits) {
+__global__ __launch_bounds__(256, WGS_PER_CU) void pat(const char* __restrict__ x, unsigned* out, int nunits, const float* __restrict__ qv) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u4 acc = {0, 0, 0, 0};
     for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
@@ -93,6 +93,66 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void pat(const char* __restrict__ 
             for (int i = 0; i < 32; i++) a[i] = LD(base + (size_t)wave * 32768 + (size_t)i * 1024 + lane * 16);
 #pragma unroll
             for (int i = 0; i < 32; i++) acc ^= a[i];
+        } else if (MODE >= 6) {     // seg128 as MODE 0, every pass staged through LDS like the scan: 16-byte writes into a row-major
+                                    // tile (pitch 144 B), wave sync, every lane reads ITS row back.  MODE 7: + the fp64 chain
+                                    // s += (q - x)^2 (q wave-uniform).  MODE 8: + an epilogue of two workgroup barriers, an LDS
+                                    // exchange and a few global stores.
+            extern __shared__ __align__(16) unsigned char smem[];
+            float* tile = reinterpret_cast<float*>(smem);
+            constexpr int PITCH = 36;
+            u4 a[8], b[8];
+            // buffer loads like the scan: one resource per unit, a 32-bit lane offset + a scalar offset per slot, nt policy
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 131072, 0x00020000);
+            const int slot_row = wave * 64 + lane / 8, slot_col = (lane % 8) * 4;
+            const int slot_off = slot_row * 512 + slot_col * 4;
+            auto bload = [&](int c, int i) { return __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, slot_off + c * 128, i * 8 * 512, 2)); };
+            double s = 0.0;
+            typedef const float __attribute__((address_space(4)))* crow_t;
+            const crow_t qrow = (crow_t)(qv + (u & 1023) * 128);
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define TILE(REG, C, NEXT)                                                                                     \
+            do {                                                                                               \
+                WSYNC();                                                                                       \
+                _Pragma("unroll") for (int i = 0; i < 8; i++)                                                  \
+                    *reinterpret_cast<u4*>(tile + (slot_row + i * 8) * PITCH + slot_col) = REG[i];             \
+                if (NEXT >= 0) { _Pragma("unroll") for (int i = 0; i < 8; i++) REG[i] = bload(NEXT < 0 ? 0 : NEXT, i); } \
+                WSYNC();                                                                                       \
+                const float* myrow = tile + tid * PITCH;                                                       \
+                _Pragma("unroll 4") for (int kk = 0; kk < 32; kk += 4) {                                       \
+                    const u4 xv = *reinterpret_cast<const u4*>(myrow + kk);                                    \
+                    if (MODE == 6) acc ^= xv;                                                                  \
+                    else {                                                                                     \
+                        _Pragma("unroll") for (int e = 0; e < 4; e++) {                                        \
+                            const double q0 = static_cast<double>(qrow[(C) * 32 + kk + e]);                    \
+                            const double x0 = static_cast<double>(__uint_as_float(xv[e]));                     \
+                            const double d0 = q0 - x0;                                                         \
+                            const double p0 = d0 * d0;                                                         \
+                            s = s + p0;                                                                        \
+                        }                                                                                      \
+                    }                                                                                          \
+                }                                                                                              \
+            } while (0)
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = bload(0, i);
+#pragma unroll
+            for (int i = 0; i < 8; i++) b[i] = bload(1, i);
+            TILE(a, 0, 2);
+            TILE(b, 1, 3);
+            TILE(a, 2, -1);
+            TILE(b, 3, -1);
+            if (MODE >= 7) { acc.x ^= (unsigned)__double_as_longlong(sqrt(s)); acc.y ^= (unsigned)(__double_as_longlong(s) >> 32); }
+            if (MODE >= 8) {
+                __shared__ unsigned s_x[4];
+                if (lane == 0) s_x[wave] = acc.x;
+                __syncthreads();
+                const unsigned m = s_x[0] ^ s_x[1] ^ s_x[2] ^ s_x[3];
+                tile[tid] = __uint_as_float(acc.y ^ m);
+                __syncthreads();
+                if (tid < 10) { out[64 + u * 16 + tid] = __float_as_uint(tile[(tid * 7) & 255]); }
+                __syncthreads();
+            }
+#undef TILE
+#undef WSYNC
         }
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) out[0] = 1;
@@ -103,15 +163,17 @@ int main(int argc, char** argv) {
     const size_t unit_set = (size_t)nunits * 131072;      // 128 MiB per launch
     const int nsets = 32;                                 // 4 GiB cycled
     char* x; unsigned* out;
-    if (hipMalloc(&x, unit_set * nsets) != hipSuccess || hipMalloc(&out, 64) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    if (hipMalloc(&x, unit_set * nsets) != hipSuccess || hipMalloc(&out, 64 + 1024 * 64 + 256) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(x, 0x5A, unit_set * nsets);
+    float* qv; hipMalloc(&qv, 1024 * 128 * 4); hipMemset(qv, 0x3C, 1024 * 128 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto run = [&](const char* name, auto kern, int grid) {
         std::vector<float> ts;
         for (int it = 0; it < 8 + 48; it++) {
             const char* p = x + (size_t)(it % nsets) * unit_set;
             hipDeviceSynchronize();
-            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, e0, e1, 0, p, out, nunits);
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 256 * 36 * 4, 0, e0, e1, 0, p, out, nunits, qv);
+            { hipError_t le = hipGetLastError(); if (le != hipSuccess && it == 0) printf("launch error: %s\n", hipGetErrorString(le)); }
             hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (it >= 8) ts.push_back(ms);
@@ -122,6 +184,10 @@ int main(int argc, char** argv) {
         printf("%-44s grid %4d  avg %6.2f us  med %6.2f us  min %6.2f us  -> %5.2f TB/s (avg)\n", name, grid, avg * 1e3, med * 1e3, ts[0] * 1e3, unit_set / (avg * 1e-3) / 1e12);
     };
     run("seg128 2 passes in flight (the scan) 4/CU", pat<0, 4>, 1024);
+    run("seg128 + LDS staging 4/CU", pat<6, 4>, 1024);
+    run("seg128 + LDS staging + fp64 chain 4/CU", pat<7, 4>, 1024);
+    run("seg128 + LDS + fp64 + epilogue 4/CU", pat<8, 4>, 1024);
+    run("seg128 2 passes in flight (again)", pat<0, 4>, 1024);
     run("seg128 1 pass in flight 4/CU", pat<4, 4>, 1024);
     run("seg256 both passes up front 2/CU", pat<1, 2>, 1024);
     run("seg256 both passes up front 2/CU grid 512", pat<1, 2>, 512);
