@@ -92,7 +92,7 @@ struct RefineArgs {
     int32_t* scored;
     RefinePartial* partial;
     int32_t* partial_cnt;
-    long long* dbg;              // FSPANN_DEBUG_STAMPS builds: [grid][16] wall_clock64 stamps of each workgroup's first unit (else unused)
+    long long* dbg;              // FSPANN_DEBUG_STAMPS builds: [grid][4 waves][16] wall_clock64 stamps of each workgroup's first unit (else unused)
 };
 
 // Stage C for one 256-row chunk (QSI:298-316): stable rank of the chunk's distances by (fp64 bits, candidate position),
@@ -100,7 +100,16 @@ struct RefineArgs {
 // `tile` = the workgroup's LDS tile, dead at this point: every wave keeps its scratch in its own 64 rows of it.
 template <typename TC, typename TQ, int PITCH>
 __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC* tile, const bool valid, const uint64_t key,
-                                                 const int32_t my_id, const int64_t qi, const int chunk, const int r0) {
+                                                 const int32_t my_id, const int64_t qi, const int chunk, const int r0,
+                                                 long long* stamps = nullptr) {
+    // debug builds: stamps go to LDS and are flushed by the caller after the unit (a global store here would sit in front of
+    // the next s_waitcnt vmcnt(0) and the stamp would measure its own latency)
+#ifdef FSPANN_DEBUG_STAMPS
+    __shared__ long long s_em_stamps[kRefRows / 64][16];
+#define EM_STAMP(i) do { if (stamps && (threadIdx.x & 63) == 0) s_em_stamps[threadIdx.x >> 6][(i)] = wall_clock64(); } while (0)
+#else
+#define EM_STAMP(i) do { (void)stamps; } while (0)
+#endif
     const int k = a.k, nchunks = a.nchunks;
     int32_t* __restrict__ out_ids = a.out_ids;
     double* __restrict__ out_dist = a.out_dist;
@@ -135,19 +144,33 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
         // below (T + 2^kCutLow) << 32.  One vector compare per step, the rest is scalar work — this epilogue is the tail of
         // the launch, every wave of a SIMD is in it at once and they share one vector pipe (an exact all-pairs rank of the
         // wave's 64 keys: ~400 vector instructions per wave, 1.5 us of the launch).
+        // (compares through the icmp builtin: its result IS the lane mask in scalar registers — one vector instruction and
+        // four scalar ones per candidate; __ballot of a bool costs two more vector instructions, and every hop between
+        // the vector and scalar pipes is a pipeline latency on this dependent chain: 1.5 us of the launch's tail as 21
+        // one-bit steps through __ballot, two bits per step here)
         constexpr int kCutLow = 10;
-        const uint32_t hi = valid ? static_cast<uint32_t>(key >> 32) : 0xFFFFFFFFu;
-        uint32_t T = 0;
+        const uint32_t hi = static_cast<uint32_t>(key >> 32);       // an invalid lane's key is all ones: never below a candidate
+        auto below = [&](const uint32_t c) { return __popcll(__builtin_amdgcn_uicmp(hi, c, 36 /* ICMP_ULT */)); };
+        uint32_t T = (below(1u << 30) < k) ? (1u << 30) : 0u;
 #pragma unroll
-        for (int b = 30; b >= kCutLow; b--) {
-            const uint32_t c = T | (1u << b);
-            T = (__popcll(__ballot(hi < c)) < k) ? c : T;
+        for (int b = 28; b >= kCutLow; b -= 2) {
+            const uint32_t c1 = T | (1u << b), c2 = T | (2u << b), c3 = T | (3u << b);
+            // the three compares of a step back to back, each into its own scalar pair: ONE trip from the vector to the scalar
+            // pipe per step (left to the compiler they all go through VCC, one trip each: 60 of the chain's 90 pipe crossings)
+            unsigned long long m1, m2, m3;
+            asm volatile("v_cmp_gt_u32_e64 %0, %3, %6\n\tv_cmp_gt_u32_e64 %1, %4, %6\n\tv_cmp_gt_u32_e64 %2, %5, %6"
+                         : "=&s"(m1), "=&s"(m2), "=&s"(m3) : "s"(c1), "s"(c2), "s"(c3), "v"(hi));
+            const int n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+            T = (n3 < k) ? c3 : (n2 < k) ? c2 : (n1 < k) ? c1 : T;
         }
+        static_assert(kCutLow % 2 == 0, "two bits per step from bit 29 down");
         const uint64_t wc = (wvalid >= k) ? ((static_cast<uint64_t>(T + (1u << kCutLow)) << 32) - 1ull) : kInvalidKey;
         if (lane == 0) s_wcut[wave] = wc;
     }
     if (lane == 0) s_wbase[wave] = wvalid;
+    EM_STAMP(6);
     __syncthreads();   // (1) keys, cuts and valid counts of all waves
+    EM_STAMP(7);
     int nvalid = 0;
     uint64_t cutk = kInvalidKey;
 #pragma unroll
@@ -175,19 +198,25 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
         // its own survivors go in ONE dense list, in candidate-position order.
         unsigned long long bm_mine = 0;
         int mybase = 0, T = 0;
+        const uint64_t cut_valid = min(cutk, kInvalidKey - 1);      // no cut at all (no wave holds k valid keys): every valid key
+        static_assert(kRefRows / 64 == 4, "four waves");
+        const uint64_t kw0 = wave_scratch(0)[lane], kw1 = wave_scratch(1)[lane], kw2 = wave_scratch(2)[lane], kw3 = wave_scratch(3)[lane];
+        unsigned long long bmw[4];
+        asm volatile("v_cmp_le_u64_e64 %0, %4, %8\n\tv_cmp_le_u64_e64 %1, %5, %8\n\tv_cmp_le_u64_e64 %2, %6, %8\n\tv_cmp_le_u64_e64 %3, %7, %8"
+                     : "=&s"(bmw[0]), "=&s"(bmw[1]), "=&s"(bmw[2]), "=&s"(bmw[3]) : "v"(kw0), "v"(kw1), "v"(kw2), "v"(kw3), "s"(cut_valid));
 #pragma unroll
-        for (int w = 0; w < kRefRows / 64; w++) {
-            const uint64_t kw = wave_scratch(w)[lane];
-            const unsigned long long bmw = __ballot(kw <= cutk && kw != kInvalidKey);
-            if (w == wave) { mybase = T; bm_mine = bmw; }
-            T += __popcll(bmw);
+        for (int w = 0; w < 4; w++) {
+            if (w == wave) { mybase = T; bm_mine = bmw[w]; }
+            T += __popcll(bmw[w]);
         }
         if ((bm_mine >> lane) & 1ull) {
             // (mbcnt = set bits of the mask below this lane: no lane mask to build, hoist and keep alive through the stream)
             const int at = mybase + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bm_mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bm_mine), 0u)));
             *surv(at) = make_uint4(static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), static_cast<uint32_t>(my_id), static_cast<uint32_t>(r0 + tid));
         }
+        EM_STAMP(8);
         __syncthreads();   // (2) the survivor list
+        EM_STAMP(9);
         // Exact rank of survivor i = #{j : (key_j, j) < (key_i, i)}, the T x T pairs spread over the WHOLE workgroup: 2^lgP
         // consecutive lanes share one i and split the j (T ~ 30: eight lanes per survivor, four pairs each), their partial
         // counts meet in a few xor-shuffles — a few dozen vector instructions per wave where every wave ranking its own
@@ -199,13 +228,29 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
         if (i < T) {
             const uint2 mk = *reinterpret_cast<const uint2*>(surv(i));
             const uint64_t ki = static_cast<uint64_t>(mk.x) | (static_cast<uint64_t>(mk.y) << 32);
-            for (int j = part; j < T; j += (1 << lgP)) {
-                const uint2 o = *reinterpret_cast<const uint2*>(surv(j));
-                const uint64_t kj = static_cast<uint64_t>(o.x) | (static_cast<uint64_t>(o.y) << 32);
-                r += (kj < ki) || (kj == ki && j < i);
+            for (int j0 = part; j0 < T; j0 += (4 << lgP)) {         // four list entries per trip, their loads issued together
+                uint2 o[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + (u << lgP);
+                    o[u] = *reinterpret_cast<const uint2*>(surv(j < T ? j : i));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + (u << lgP);
+                    const uint64_t kj = static_cast<uint64_t>(o[u].x) | (static_cast<uint64_t>(o[u].y) << 32);
+                    r += (j < T) && ((kj < ki) || (kj == ki && j < i));
+                }
             }
         }
-        for (int o = (1 << lgP) >> 1; o >= 1; o >>= 1) r += __shfl_xor(r, o);
+        // the 2^lgP partial counts of a survivor meet: inside a row of 16 lanes through DPP (no LDS round trip), beyond through shuffles
+        if (lgP >= 1) r += __builtin_amdgcn_update_dpp(0, r, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+        if (lgP >= 2) r += __builtin_amdgcn_update_dpp(0, r, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+        if (lgP >= 3) r += __builtin_amdgcn_update_dpp(0, r, 0x141, 0xF, 0xF, false);    // row_half_mirror
+        if (lgP >= 4) r += __builtin_amdgcn_update_dpp(0, r, 0x140, 0xF, 0xF, false);    // row_mirror
+        if (lgP >= 5) r += __shfl_xor(r, 16);
+        if (lgP >= 6) r += __shfl_xor(r, 32);
+        EM_STAMP(10);
         if (i < T && part == 0 && r < eff) {
             const uint4 me = *surv(i);
             emit(r, static_cast<uint64_t>(me.x) | (static_cast<uint64_t>(me.y) << 32), static_cast<int32_t>(me.z), static_cast<int32_t>(me.w));
@@ -235,6 +280,11 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
         partial_cnt[(qi * nchunks + chunk) * 2 + 0] = eff;
         partial_cnt[(qi * nchunks + chunk) * 2 + 1] = nvalid;
     }
+    EM_STAMP(11);
+#ifdef FSPANN_DEBUG_STAMPS
+    if (stamps && (threadIdx.x & 63) == 0) for (int i = 6; i <= 11; i++) stamps[i] = s_em_stamps[threadIdx.x >> 6][i];
+#endif
+#undef EM_STAMP
 }
 
 // One workgroup (kRefRows threads) = one 256-row chunk of one query: block `bidx` of nq * nchunks.  `smem` = dynamic LDS.
@@ -510,7 +560,8 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
 #define FSP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 #ifdef FSPANN_DEBUG_STAMPS
-#define RS_STAMP(i) do { if (a.dbg && tid == 0 && first_unit) a.dbg[wg * 16 + (i)] = wall_clock64(); } while (0)
+    __shared__ long long s_rs_stamps[kRefRows / 64][16];
+#define RS_STAMP(i) do { if (a.dbg && lane == 0 && first_unit) s_rs_stamps[wave][(i)] = wall_clock64(); } while (0)
 #else
 #define RS_STAMP(i) do { } while (0)
 #endif
@@ -553,9 +604,6 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         typedef const TQ __attribute__((address_space(4)))* const_row_t;
         const const_row_t qrow = (const_row_t)(a.q + qi * d);
         const int rows_here = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
-#ifdef FSPANN_AB_NOHEAD
-        const int32_t my_id_raw = tid; int cnt_raw = static_cast<int>(B); bool qnf = false; (void)counts_fresh;
-#else
         const int32_t my_id_raw = (tid < rows_here) ? cand_ids[qi * B + r0 + tid] : -1;
         int cnt_raw;
         if (counts_fresh) cnt_raw = __hip_atomic_load(const_cast<int32_t*>(a.cand_count) + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -563,7 +611,6 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         // QSI.java:137-140: a non-finite query gives an empty result.  Every wave looks at the whole query itself.
         bool qnf = false;
         for (int i = lane; i < d; i += 64) qnf = qnf || !__builtin_isfinite(qrow[i]);
-#endif
         // The count, this lane's id and the query check are REQUESTED here but first USED after the last tile: the scan
         // below runs over every row the block holds (tid < rows_here) and the count only decides, in the epilogue, which
         // rows are scored — so no tile waits for this round trip.
@@ -623,12 +670,15 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         uint64_t key = kInvalidKey;
         if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
         RS_STAMP(5);
-#ifdef FSPANN_AB_NOEMIT
-        if (valid && tid < a.k) { a.out_ids[qi * a.k + tid] = my_id; a.out_dist[qi * a.k + tid] = __longlong_as_double(static_cast<long long>(key)); }
+#ifdef FSPANN_DEBUG_STAMPS
+        refine_topk_emit<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, chunk, r0, (a.dbg && first_unit) ? a.dbg + (wg * 4 + wave) * 16 : nullptr);
 #else
         refine_topk_emit<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, chunk, r0);
 #endif
-        RS_STAMP(6);
+        RS_STAMP(12);
+#ifdef FSPANN_DEBUG_STAMPS
+        if (a.dbg && lane == 0 && first_unit) { for (int i = 0; i <= 5; i++) a.dbg[(wg * 4 + wave) * 16 + i] = s_rs_stamps[wave][i]; a.dbg[(wg * 4 + wave) * 16 + 12] = s_rs_stamps[wave][12]; }
+#endif
         __syncthreads();       // every wave has finished reading the other waves' scratch before the tile is written again
         first_unit = false;
     }

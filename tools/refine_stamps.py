@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g  # noqa: E402
 
 pkg = g.load_package()
+if os.environ.get('AB_LIB'): pkg._native._SO = os.environ['AB_LIB']   # a variant build (dev experiments)
 L = pkg._native.lib()
 L.fspann_debug_route_stamps.argtypes = [C.c_void_p, C.c_void_p]
 dev = torch.device("cuda", 0)
@@ -27,7 +28,7 @@ od = torch.zeros((Q, k), dtype=torch.float64, device=dev)
 oc = torch.zeros(Q, dtype=torch.int32, device=dev)
 sc = torch.zeros(Q, dtype=torch.int32, device=dev)
 G = 4 * 256
-dbg = torch.zeros((G, 16), dtype=torch.int64, device=dev)
+dbg = torch.zeros((G * 4, 16), dtype=torch.int64, device=dev)   # [workgroup][wave][16]
 
 
 def run(b):
@@ -45,19 +46,25 @@ a = dbg.cpu().numpy().astype(np.float64)
 a = a[a[:, 0] > 0]
 TICK = 0.01
 t0 = a[:, 0].min()
-names = ["start", "first two tiles requested", "tile 0 consumed", "tile 1 consumed", "all tiles consumed", "keys ready", "top-K written"]
-print("workgroups with stamps:", len(a))
+names = ["start", "first two tiles requested", "tile 0 consumed", "tile 1 consumed", "all tiles consumed", "keys ready",
+         "cut bisected", "barrier 1 passed", "survivors listed", "barrier 2 passed", "ranked", "written", "after emit"]
+print("waves with stamps:", len(a))
 for i, nm in enumerate(names):
     v = (a[:, i] - t0) * TICK
     print("%-28s min %6.2f  p10 %6.2f  med %6.2f  p90 %6.2f  max %6.2f us" % (nm, v.min(), np.percentile(v, 10), np.median(v), np.percentile(v, 90), v.max()))
 for i in range(1, len(names)):
     dt = (a[:, i] - a[:, i - 1]) * TICK
     print("  %-26s <- %-26s med %5.2f  p90 %5.2f  max %5.2f us" % (names[i], names[i - 1], np.median(dt), np.percentile(dt, 90), dt.max()))
-# per XCD (workgroup id mod 8, the dispatcher's round-robin): when its workgroups have consumed their tiles / written their top-K
-full = dbg.cpu().numpy().astype(np.float64)
+# wave skew inside a workgroup: spread of "keys ready" over its four waves
+full = dbg.cpu().numpy().astype(np.float64).reshape(-1, 4, 16)
+ok = full[:, :, 0].min(axis=1) > 0
+kr = full[ok][:, :, 5]
+print("keys ready, spread over the 4 waves of a workgroup: med %.2f p90 %.2f max %.2f us" % (
+    np.median(kr.max(axis=1) - kr.min(axis=1)) * TICK, np.percentile(kr.max(axis=1) - kr.min(axis=1), 90) * TICK, (kr.max(axis=1) - kr.min(axis=1)).max() * TICK))
+last = full[ok][:, :, 12].max(axis=1)
+print("workgroup end (last wave after emit): med %.2f p90 %.2f max %.2f us" % ((np.median(last) - t0) * TICK, (np.percentile(last, 90) - t0) * TICK, (last.max() - t0) * TICK))
 for x in range(8):
-    rows = full[x::8]
-    rows = rows[rows[:, 0] > 0]
+    rows = full[ok][x::8]
     if len(rows):
-        print("XCD %d: tiles consumed med %6.2f max %6.2f | top-K written med %6.2f max %6.2f us" % (
-            x, (np.median(rows[:, 4]) - t0) * TICK, (rows[:, 4].max() - t0) * TICK, (np.median(rows[:, 6]) - t0) * TICK, (rows[:, 6].max() - t0) * TICK))
+        print("XCD %d: tiles consumed med %6.2f max %6.2f | end med %6.2f max %6.2f us" % (
+            x, (np.median(rows[:, :, 4]) - t0) * TICK, (rows[:, :, 4].max() - t0) * TICK, (np.median(rows[:, :, 12]) - t0) * TICK, (rows[:, :, 12].max() - t0) * TICK))
