@@ -470,8 +470,20 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     if (lrc) return lrc;
     FSP_HIP(hipGetLastError());
     if (nchunks > 1) {
-        hipLaunchKernelGGL(refine_merge_kernel, dim3(static_cast<unsigned>(nq)), dim3(256), 0, c->stream, partial, pcnt,
-                           nchunks, k, out_ids, out_dist, out_count, scored);
+        // all keys of a query's partial lists in LDS when they fit (two workgroups per CU at least)
+        const size_t mlds = static_cast<size_t>(nchunks) * k * 8 + static_cast<size_t>(nchunks) * 4 + 16;
+        if (mlds <= 72 * 1024) {
+            auto mk = refine_merge_kernel<true>;
+            if (mlds > 64 * 1024 && !(c->attr_mask & 16384u)) {
+                FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mk), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+                c->attr_mask |= 16384u;
+            }
+            hipLaunchKernelGGL(mk, dim3(static_cast<unsigned>(nq)), dim3(256), mlds, c->stream, partial, pcnt,
+                               nchunks, k, out_ids, out_dist, out_count, scored);
+        } else {
+            hipLaunchKernelGGL(refine_merge_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, c->stream, partial, pcnt,
+                               nchunks, k, out_ids, out_dist, out_count, scored);
+        }
         FSP_HIP(hipGetLastError());
     }
     return FSPANN_OK;

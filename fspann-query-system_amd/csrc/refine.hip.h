@@ -697,12 +697,20 @@ __global__ __launch_bounds__(kRefRows, (GATHER ? 2 : 4)) void refine_stream_kern
 // Merge of per-chunk sorted top-k lists (B > kRefRows).  Each list is sorted by
 // (key, pos) and chunks hold disjoint, increasing pos ranges, so the global rank of
 // an element is its own rank plus, per other chunk, an upper/lower bound.
+// KEYS_IN_LDS: the keys of all lists (nchunks * k * 8 bytes) and the list lengths are staged in LDS first, so the binary
+// searches — nchunks - 1 per element, ~7 dependent reads each — run at LDS latency instead of L2 latency (the shipped
+// profiles: 32 / 86 lists of 100; 215 / 516 us per 1 024 queries from global memory).  The host picks the variant by size.
+template <bool KEYS_IN_LDS>
 __global__ __launch_bounds__(256) void refine_merge_kernel(const RefinePartial* __restrict__ partial,
                                                            const int32_t* __restrict__ partial_cnt, int nchunks, int k,
                                                            int32_t* __restrict__ out_ids, double* __restrict__ out_dist,
                                                            int32_t* __restrict__ out_count, int32_t* __restrict__ scored) {
+    extern __shared__ __align__(16) unsigned char merge_smem[];
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(merge_smem);                       // [nchunks][k]
+    int32_t* s_cnt = reinterpret_cast<int32_t*>(s_keys + static_cast<size_t>(nchunks) * k);   // [nchunks]
     const int64_t qi = blockIdx.x;
     const int tid = threadIdx.x;
+    const int nelem = nchunks * k;
     __shared__ int s_total, s_nvalid;
     if (tid == 0) {
         int t = 0, nv = 0;
@@ -713,32 +721,36 @@ __global__ __launch_bounds__(256) void refine_merge_kernel(const RefinePartial* 
         s_total = t;
         s_nvalid = nv;
     }
+    if constexpr (KEYS_IN_LDS) {
+        for (int c = tid; c < nchunks; c += blockDim.x) s_cnt[c] = partial_cnt[(qi * nchunks + c) * 2];
+        for (int e = tid; e < nelem; e += blockDim.x) s_keys[e] = partial[qi * nelem + e].key;     // entries beyond a list's length are never read
+    }
     __syncthreads();
     const int eff = min(k, s_total);
-    const int nelem = nchunks * k;
     for (int e = tid; e < nelem; e += blockDim.x) {
         const int c = e / k, rk = e - c * k;
-        const int cc = partial_cnt[(qi * nchunks + c) * 2];
+        const int cc = KEYS_IN_LDS ? s_cnt[c] : partial_cnt[(qi * nchunks + c) * 2];
         if (rk >= cc) continue;
-        const RefinePartial me = partial[(qi * nchunks + c) * k + rk];
+        const uint64_t mykey = KEYS_IN_LDS ? s_keys[e] : partial[qi * nelem + e].key;
         int rank = rk;
         for (int c2 = 0; c2 < nchunks && rank < eff; c2++) {
             if (c2 == c) continue;
-            const int n2 = partial_cnt[(qi * nchunks + c2) * 2];
+            const int n2 = KEYS_IN_LDS ? s_cnt[c2] : partial_cnt[(qi * nchunks + c2) * 2];
             const RefinePartial* lst = partial + (qi * nchunks + c2) * k;
+            const uint64_t* lk = s_keys + c2 * k;
             // c2 < c: count keys <= me.key (earlier positions win ties); c2 > c: keys < me.key
             int lo = 0, hi = n2;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                const uint64_t km = lst[mid].key;
-                const bool before = (c2 < c) ? (km <= me.key) : (km < me.key);
+                const uint64_t km = KEYS_IN_LDS ? lk[mid] : lst[mid].key;
+                const bool before = (c2 < c) ? (km <= mykey) : (km < mykey);
                 if (before) lo = mid + 1; else hi = mid;
             }
             rank += lo;
         }
         if (rank < eff) {
-            out_ids[qi * k + rank] = me.id;
-            out_dist[qi * k + rank] = __longlong_as_double(static_cast<long long>(me.key));
+            out_ids[qi * k + rank] = partial[qi * nelem + e].id;
+            out_dist[qi * k + rank] = __longlong_as_double(static_cast<long long>(mykey));
         }
     }
     for (int i = eff + tid; i < k; i += blockDim.x) {

@@ -43,7 +43,8 @@ constexpr int lz_sort_max(int kEnt) { return kEnt - 128; }       // entries the 
 constexpr size_t lz_lds_bytes(int kEnt, int TD, int P) {         // dynamic LDS of route_lazy_run (host and device agree through this)
     return static_cast<size_t>(lz_ht_size(kEnt)) * 8 + static_cast<size_t>(TD) * P * 16 + static_cast<size_t>(kEnt) * 4 + 4096 +
            (static_cast<size_t>(TD) * P + 2) * 8 + (static_cast<size_t>(TD) * P + 1) * 4 + 8 + static_cast<size_t>(TD) * 8 +
-           ((static_cast<size_t>(TD) * P * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kEnt) * 2 * 3 + static_cast<size_t>(TD) * 4 + 16;
+           ((static_cast<size_t>(TD) * P * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kEnt) * 2 * 3 + static_cast<size_t>(kEnt) * 4 +
+           static_cast<size_t>(TD) * 4 + 16;
 }
 // probed partitions in flight per wave (lz_stage_u) and partitions of the crossing level one wave keeps in registers (lz_keep).
 // (Halving both fits the small class into 64 registers = 8 workgroups per CU, but a lone launch then takes 52 us instead of 42
@@ -117,6 +118,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     uint16_t* ulist = reinterpret_cast<uint16_t*>(smem + o);     o += static_cast<size_t>(kLzEntries) * 2;   // hash slots of the entries
     uint16_t* rk = reinterpret_cast<uint16_t*>(smem + o);        o += static_cast<size_t>(kEnt) * 2;   // entries per (score, bucket) rank: > 1 = collision
     uint16_t* lrank = reinterpret_cast<uint16_t*>(smem + o);     o += static_cast<size_t>(kEnt) * 2;   // (score, bucket) rank of each entry
+    uint32_t* gk = reinterpret_cast<uint32_t*>(smem + o);        o += static_cast<size_t>(kEnt) * 4;   // the keys grouped by their top bits (rank pass)
     int32_t* nprobe_l = reinterpret_cast<int32_t*>(smem + o);    // [TD] fused probe: partitions probed per table
     // collision records alias the histogram (free once the levels are in): element, prefix rank, id, sequence
     int32_t* c_elem = bins;
@@ -460,34 +462,53 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         if (nsel > kLzSortMax) overflow = true;
         if (!overflow) {
             const int nout = min(nsel, prm.limit);
-            // element i is ranked by `parts` cooperating lanes, each over a slice of the keys.  Rounds: as many elements as
-            // lanes allow, then the few left over with more lanes each (257 entries = 256 with one lane + 1 with 16).
+            // Rank of an entry = #{keys < its key} (equal keys share a rank and are settled in step 4).  All-pairs over the
+            // ~270 keys was a quarter of this kernel's vector instructions — and with several launches in flight the kernel is
+            // bound by vector issue, not latency.  Instead: counting sort on the keys' TOP bits — (score above
+            // the first level's, six bucket bits) -> 1 024 groups of ~1 key —, then every entry counts the smaller keys of its OWN
+            // group only.  Three more barriers, a tenth of the instructions.
+            const uint32_t smin = pkv[ord[0]].x >> 16;                       // the lowest distance level: no entry scores below it
+            auto coarse = [&](const uint32_t key) -> uint32_t { return min((key - (smin << kBucketBits)) >> (kBucketBits - 6), 1023u); };
             for (int i = tid; i < kEnt; i += nthreads) pre[i] = (i < nsel) ? static_cast<uint32_t>(ht[ulist[i]]) : 0xFFFFFFFFu;
             for (int i = tid; i < kEnt / 2; i += nthreads) reinterpret_cast<uint32_t*>(rk)[i] = 0u;
+            for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;
             __syncthreads();
             LZ_STAMP(4);
-            for (int e0 = 0; e0 < nsel;) {
-                const int rem = nsel - e0;
-                int parts = 1;
-                while (parts < 16 && rem * parts * 2 <= nthreads) parts <<= 1;
-                const int cnt = min(rem, nthreads / parts);
-                const int len = (((nsel + parts - 1) / parts) + 7) & ~7;   // slice length, multiple of 8; parts * len <= 1024
-                const int i = e0 + tid / parts, part = tid % parts;
-                const bool act = (tid / parts) < cnt;
-                const uint32_t my = act ? pre[i] : 0u;
-                int lt = 0;
-                const uint4* p4 = reinterpret_cast<const uint4*>(pre + part * len);
-                for (int j = 0; j < len / 4; j += 2) {
-                    const uint4 a = p4[j], b = p4[j + 1];
-                    lt += (a.x < my) + (a.y < my) + (a.z < my) + (a.w < my) + (b.x < my) + (b.y < my) + (b.z < my) + (b.w < my);
+            for (int i = tid; i < nsel; i += nthreads) atomicAdd(&bins[coarse(pre[i])], 1);
+            __syncthreads();
+            if (wave == 0) {                        // exclusive prefix of the 1 024 counts, in place: 16 bins per lane
+                int4* b4 = reinterpret_cast<int4*>(bins) + lane * 4;
+                int4 v[4] = {b4[0], b4[1], b4[2], b4[3]};
+                int* vals = reinterpret_cast<int*>(v);
+                int sum = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) { const int t = vals[i]; vals[i] = sum; sum += t; }
+                int incl = sum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(incl, off);
+                    if (lane >= off) incl += t;
                 }
-                for (int off = parts >> 1; off > 0; off >>= 1) lt += __shfl_xor(lt, off);
-                if (act && part == 0) {
-                    // equal keys share their rank: count the entries per rank (2 x u16 per word)
-                    atomicAdd(reinterpret_cast<uint32_t*>(rk) + (lt >> 1), 1u << ((lt & 1) * 16));
-                    lrank[i] = static_cast<uint16_t>(lt);
-                }
-                e0 += cnt;
+                const int excl = incl - sum;
+#pragma unroll
+                for (int i = 0; i < 16; i++) vals[i] += excl;
+                b4[0] = v[0]; b4[1] = v[1]; b4[2] = v[2]; b4[3] = v[3];
+            }
+            __syncthreads();
+            for (int i = tid; i < nsel; i += nthreads) {
+                const uint32_t my = pre[i];
+                gk[atomicAdd(&bins[coarse(my)], 1)] = my;          // afterwards bins[c] = END of group c = start of group c + 1
+            }
+            __syncthreads();
+            for (int i = tid; i < nsel; i += nthreads) {
+                const uint32_t my = pre[i];
+                const uint32_t c = coarse(my);
+                const int g1 = bins[c], g0 = c ? bins[c - 1] : 0;
+                int lt = g0;
+                for (int j = g0; j < g1; j++) lt += gk[j] < my;
+                // equal keys share their rank: count the entries per rank (2 x u16 per word)
+                atomicAdd(reinterpret_cast<uint32_t*>(rk) + (lt >> 1), 1u << ((lt & 1) * 16));
+                lrank[i] = static_cast<uint16_t>(lt);
             }
             __syncthreads();
             // classify only: the global result stores come last (a workgroup barrier waits for outstanding stores, so a
