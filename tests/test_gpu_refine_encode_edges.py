@@ -52,6 +52,47 @@ def test_refine_ties_are_stable(pkg, oracle):
         assert all(res["ids"][i][j] < res["ids"][i][j + 1] for j in same)      # ties in ascending position
 
 
+def test_refine_topk_epilogue_corner_cases(pkg, oracle):
+    """The scan's top-K epilogue (per-wave bisected cut, dense survivor list, pair-parallel exact rank): every candidate equal
+    (all 256 survive the cut: one lane per survivor), a zero distance (top word 0), distances spread over the whole fp64
+    exponent range inside one chunk with a small k (the bisect walks every bit), fewer valid rows than k in three of four
+    waves, and k = 32 / 33 on either side of the filter's limit."""
+    rng = np.random.default_rng(11)
+    B, d = 256, 8
+    q = rng.standard_normal((6, d))
+    cand = rng.standard_normal((6, B, d))
+    cand[0, :, :] = cand[0, 0, :]                                   # all equal
+    cand[1, 17, :] = q[1]                                           # one exact hit: distance 0
+    mags = 10.0 ** rng.uniform(-150, 150, B)                        # squares span 1e-300 .. 1e300
+    cand[2] = q[2] + np.outer(mags, np.eye(d)[0])
+    cand[3, :, 0] = np.where(np.arange(B) % 64 < 3, cand[3, :, 0], np.nan)     # three valid rows per wave
+    cand[4, 64:, 1] = np.inf                                        # only the first wave holds valid rows
+    ids = np.tile(np.arange(B, dtype=np.int32), (6, 1))
+    cnt = np.full(6, B, np.int32)
+    for k in (1, 5, 10, 32, 33):
+        _check_refine(pkg, oracle, q, cand, ids, cnt, k, np.float64)
+    cand32 = np.clip(cand, -1e30, 1e30)
+    cand32[3, :, 0] = np.where(np.arange(B) % 64 < 3, rng.standard_normal(B), np.nan)
+    cand32[4, 64:, 1] = np.inf
+    for k in (1, 10, 32):
+        _check_refine(pkg, oracle, q, cand32, ids, cnt, k, np.float32)
+
+
+def test_refine_merge_of_many_partial_lists(pkg, oracle):
+    """B > 256: per-chunk top-k lists merged by refine_merge_kernel — with the keys staged in LDS (<= 72 KB: 32 lists of 100)
+    and from global memory beyond that (118 lists of 100), ties across chunks included."""
+    rng = np.random.default_rng(12)
+    for B, k, d in ((8000, 100, 8), (30000, 100, 4), (30000, 7, 4)):
+        nq = 3
+        q = rng.standard_normal((nq, d))
+        base = rng.standard_normal((nq, 40, d))
+        cand = np.stack([base[i][rng.integers(0, 40, B)] for i in range(nq)])      # 40 distinct rows: ties in every chunk
+        cand[1] = rng.standard_normal((B, d))
+        ids = np.tile(np.arange(B, dtype=np.int32), (nq, 1))
+        cnt = np.array([B, B - 300, 5], np.int32)
+        _check_refine(pkg, oracle, q, cand, ids, cnt, k)
+
+
 def test_refine_nonfinite(pkg, oracle):
     rng = np.random.default_rng(2)
     nq, B, d, k = 4, 256, 32, 10
