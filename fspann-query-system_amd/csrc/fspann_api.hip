@@ -628,6 +628,13 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm_refs.load() > 0) {
+        // a communicator still launches on this context's stream (fspann_allgather_topk_dev): the context goes with the last
+        // of them (fspann_comm_destroy) instead of leaving it a dangling pointer
+        c->destroy_deferred.store(true);
+        if (c->comm_refs.load() > 0) return;
+        if (!c->destroy_deferred.exchange(false)) return;      // the communicator went in between and took the destroy with it
+    }
     fspann_ctx* parent = c->share_parent;
     {
         // the family's bookkeeping (clones alive, owner gone) changes under the OWNER's lock: clones are driven — and destroyed —
@@ -2276,6 +2283,7 @@ int fspann_comm_create(fspann_ctx* c, const void* unique_id, int world, int rank
         return fail(FSPANN_E_DEVICE, "ncclCommInitRank(world %d, rank %d): %s", world, rank, rccl_err(a, rc));
     }
     m->ctx = c; m->world = world; m->rank = rank;
+    c->comm_refs.fetch_add(1);
     *out = m;
     return FSPANN_OK;
 }
@@ -2287,7 +2295,10 @@ int fspann_comm_destroy(fspann_comm* m) {
         if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
         (void)a->CommDestroy(m->nccl);
     }
+    fspann_ctx* c = m->ctx;
     delete m;
+    // the context was destroyed while this communicator held it: the last holder finishes that destroy
+    if (c && c->comm_refs.fetch_sub(1) == 1 && c->destroy_deferred.exchange(false)) fspann_ctx_destroy(c);
     return FSPANN_OK;
 }
 

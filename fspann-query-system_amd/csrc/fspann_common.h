@@ -186,6 +186,7 @@ struct fspann_ctx {
     std::atomic<int> share_children{0};  // clones alive; the shared state may not change while > 0 (changed under the owner's `mu`)
     bool zombie = false;                 // destroyed by its owner while clones were alive: freed with the last clone
     std::atomic<int> comm_refs{0};       // fspann_comm objects that hold this context (it must outlive them)
+    std::atomic<bool> destroy_deferred{false};   // fspann_ctx_destroy came while a communicator still held the context: the last fspann_comm_destroy finishes it
     // incremental Setup (fspann_build_begin / _append / _finish): codes of the rows appended so far stay in HBM
     int64_t bld_n = 0, bld_done = -1;    // bld_done < 0: no build in progress
     fspann::DevBuf bld_codes;

@@ -389,6 +389,8 @@ size_t fspann_topk_bytes(int64_t nq, int k);
 size_t fspann_topk_dist_offset(int64_t nq, int k);
 int fspann_comm_available(void);   /* 1 if librccl could be bound in this process (lets all ranks agree before the collective create) */
 int fspann_comm_unique_id(void* id_out /* FSPANN_UNIQUE_ID_BYTES */);
+/* The communicator launches on ctx's stream and keeps ctx alive: an fspann_ctx_destroy(ctx) that comes first is finished by the
+ * last fspann_comm_destroy. */
 int fspann_comm_create(fspann_ctx* ctx, const void* unique_id, int world, int rank, fspann_comm** out);
 int fspann_comm_destroy(fspann_comm* comm);
 int fspann_comm_info(fspann_comm* comm, int* world, int* rank, const char** library);

@@ -81,3 +81,31 @@ def test_comm_c_abi_without_torch_distributed(pkg):
         L.fspann_dev_free(ctx.handle, a)
         L.fspann_dev_free(ctx.handle, b)
         L.fspann_comm_destroy(h)
+
+
+def test_context_destroyed_before_its_communicator(pkg):
+    """A communicator launches on its context's stream: destroying the context first must not leave it a dangling pointer —
+    the context lives until the last fspann_comm_destroy (the all-gather still works in between)."""
+    L = pkg._native.lib()
+    cfg = pkg.PaperRuntimeConfig(tables=1, divisions=1, m=8, lambda_=2, dim=8, refinement_limit=16)
+    ctx = pkg.FspannContext(cfg, 0)
+    uid = (C.c_char * 128)()
+    pkg._native.check(L.fspann_comm_unique_id(uid))
+    h = C.c_void_p()
+    pkg._native.check(L.fspann_comm_create(ctx.handle, uid, 1, 0, C.byref(h)))
+    raw = ctx.handle
+    nq, k = 5, 3
+    nb = L.fspann_topk_bytes(nq, k)
+    a, b = C.c_void_p(), C.c_void_p()
+    pkg._native.check(L.fspann_dev_alloc(raw, nb, C.byref(a)))
+    pkg._native.check(L.fspann_dev_alloc(raw, nb, C.byref(b)))
+    src = np.arange(nb, dtype=np.uint8)
+    pkg._native.check(L.fspann_h2d(raw, a, src.ctypes.data_as(C.c_void_p), nb))
+    ctx.close()                                               # fspann_ctx_destroy: deferred, the communicator holds the context
+    pkg._native.check(L.fspann_allgather_topk_dev(h, nq, k, a, b))
+    got = np.zeros(nb, np.uint8)
+    pkg._native.check(L.fspann_d2h(raw, got.ctypes.data_as(C.c_void_p), b, nb))
+    assert np.array_equal(got, src)
+    L.fspann_dev_free(raw, a)
+    L.fspann_dev_free(raw, b)
+    assert L.fspann_comm_destroy(h) == 0                      # the last holder finishes the destroy

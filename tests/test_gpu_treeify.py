@@ -219,3 +219,34 @@ def test_search_call_is_completed_for_flagged_queries(pkg, oracle):
         assert np.array_equal(np.where(np.arange(B)[None] < ref["sel_count"][:, None], sel.cpu().numpy(), -1), ref["sel"][:, :B])
         assert np.array_equal(oi.cpu().numpy(), ref["ids"]) and np.array_equal(od.cpu().numpy(), ref["dist"])
         assert np.array_equal(oc.cpu().numpy(), ref["count"])
+
+
+def test_host_pipeline_answers_flagged_queries(pkg, oracle):
+    """The native host pipeline (Route | AES-GCM open | Refine) with hashCodes crowded into five bins: every query's map treeifies.
+    Stage A resolves the flagged queries with the host model before their candidate ids go to the decrypt threads — the results
+    equal oracle.search, nothing is reported unmodelled, no query comes back empty."""
+    from fspann_amd import hostpipe
+    n, d, B, K = 20000, 16, 64, 5
+    sc = make_scene(oracle, n=n, d=d, T=6, D=1, m=12, lam=2, B=B, seed=91)
+    o = sc["oracle"]
+    jh = _crowded_distinct_hashes(np.random.default_rng(5), n, 5, oracle.table_size_for(20000))
+    o.set_id_meta(n, jh)
+    o.build_index(sc["X64"])
+    o.set_store(sc["X64"])
+    batches = [sc["rng"].standard_normal((nq, d)).astype(np.float32) for nq in (40, 9, 40)]
+    assert o.route_treeified(o.encode(batches[0].astype(np.float64))).all()
+    with _ctx(pkg, sc, jh) as ctx, hostpipe.PointStore(n, d) as ps:
+        _import(ctx, o)
+        ps.encrypt(sc["X"], threads=8)
+        with hostpipe.Pipeline(ctx, ps, 40, B, K, host_threads=8) as pl:
+            out = []
+            for qb in batches:
+                pl.submit(qb)
+            while pl.in_flight:
+                out.append(pl.collect())
+        assert ctx.unmodelled_queries() == 0
+    for qb, res in zip(batches, out):
+        ref = o.search(qb.astype(np.float64), K)
+        assert (res["count"] == ref["count"]).all() and (res["count"] > 0).all()
+        assert np.array_equal(res["ids"], ref["ids"]) and np.array_equal(res["dist"], ref["dist"])
+    assert not o.unmodelled
