@@ -21,6 +21,7 @@ import java.util.*;
  *   quick      Coding.buildRandomG / H / C for the CodingQuickCheck input
  *   hashcode   String.hashCode of decimal ordinals
  *   hashmap    iteration order of HashMap<String,Long>(cap) after a put sequence (incl. resize and value updates)
+ *   hashtree   the same with ids crowded into one bin: treeifyBin, putTreeVal, split / untreeify on resize
  *   pq         PriorityQueue<long[]>(comparingLong(a -> a[1])) poll order with ties
  *   key        GreedyPartitioner.computeKey / hamming on given BitSets
  *   build      GreedyPartitioner.build on a small id->code map (partition ids, min/max keys, representative)
@@ -60,6 +61,21 @@ public final class GoldenDumper {
             for (int i = 0; i < 200; i++) m.put(Long.toString((i * 37L) % 1009), (long) i);
             m.put("37", -1L);
             StringBuilder sb = new StringBuilder("hashmap " + cap);
+            for (String k : m.keySet()) sb.append(' ').append(k);
+            System.out.println(sb);
+        }
+        // Tree bins (HashMap.TreeNode): decimal ids crowded into one bin of a 64-slot table -> treeifyBin at the ninth, putTreeVal
+        // after it, a resize to 128 in the middle (split: halves stay trees or untreeify).  The iteration order of such a map is
+        // what the library's host model (host/java_hashmap.hpp) and the oracle's JHashMap must reproduce.
+        for (int bin : new int[]{5, 41}) {
+            Map<String, Long> m = new HashMap<>(64);
+            int crowded = 0;
+            for (int i = 0; crowded < 40; i++) {
+                int h = String.valueOf(i).hashCode();
+                if (((h ^ (h >>> 16)) & 63) == bin) { m.put(String.valueOf(i), (long) i); crowded++; }
+                if (i % 97 == 0) m.put(String.valueOf(1000003 + i), 0L);          // spread-out ids in between: the map passes 48 entries
+            }
+            StringBuilder sb = new StringBuilder("hashtree " + bin);
             for (String k : m.keySet()) sb.append(' ').append(k);
             System.out.println(sb);
         }

@@ -38,6 +38,19 @@ def oracle_lines():
                 keys.append(k)
         order, _, unm = O.hashmap_order(cap, np.array(keys, np.int32), np.array([O.string_hash(str(k)) for k in keys], np.int32))
         out.append("hashmap %d " % cap + " ".join(str(int(k)) for k in order) + (" UNMODELLED" if unm else ""))
+    for b in (5, 41):                                                       # tree bins: see GoldenDumper.java
+        keys, crowded, i = [], 0, 0
+        while crowded < 40:
+            h = O.string_hash(str(i)) & 0xFFFFFFFF
+            if ((h ^ (h >> 16)) & 63) == b:
+                keys.append(i)
+                crowded += 1
+            if i % 97 == 0:
+                keys.append(1000003 + i)
+            i += 1
+        order, _, tree, unm = O.hashmap_order_ex(64, np.array(keys, np.int32), np.array([O.string_hash(str(k)) for k in keys], np.int32), True)
+        assert tree and not unm
+        out.append("hashtree %d " % b + " ".join(str(int(k)) for k in order))
     for ops in ([5, -1, 3, 3, -1, -1], [5, -1, 3, 4, -1, 4, -1, -1], [5, -1, 3, 4, -1, 2, -1, -1], [7, 7, 7, -1, 7, -1, -1, -1]):
         out.append("pq " + " ".join(str(int(x)) for x in O.pq_trace(ops)))
     out.append("key %d %d %d" % (O.compute_key(np.array([0b1011], np.uint64)), O.compute_key(np.array([1 << 63, 1], np.uint64)),
