@@ -436,7 +436,7 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     const int stream_wgs = (c->knob_refine_stream >= 0) ? std::min(c->knob_refine_stream, GATHER ? 3 : 4) : (GATHER ? 3 : 4);
     if constexpr (DC * sizeof(TC) == 128) if (vec && stream_wgs > 0 && nq * nchunks < (int64_t(1) << 31)) {
         // the scan as a stream: knob_refine_stream workgroups per CU, each walking several (query, chunk) units with the loads
-        // of the next two tiles in flight across unit boundaries (refine_stream_run)
+        // of the next tile in flight across unit boundaries (refine_stream_run)
         const int64_t units = nq * nchunks;
         const unsigned sgrid = static_cast<unsigned>(std::min<int64_t>(units, static_cast<int64_t>(c->num_cus) * stream_wgs));
         const bool timed = c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size();

@@ -431,13 +431,13 @@ __global__ __launch_bounds__(kRefRows, (DC * sizeof(TC) <= 128 ? 4 : (DC * sizeo
 
 // ------------------------------------------------------------------------------------------------------------------
 // The same scan as a STREAM: one workgroup walks the units (query, 256-row chunk) u = wg, wg + nwg, wg + 2 nwg, ... and
-// keeps the row loads of the next TWO tiles in flight at all times — across unit boundaries, so the loads of the next
+// keeps the row loads of the next tile in flight at all times — across unit boundaries, so the loads of the next
 // query are under way while this query's top-K is ranked and written.
 //
 // Why: with one workgroup per query (refine_scan_block) every workgroup of the launch is in the same phase at the same
 // time — all wait for their ids, all stream, all rank — and HBM idles during the first and the last phase; and inside
 // tick_kernel each of those workgroups holds one of the CU's four slots for ~25 us, most of it waiting.  As a stream, a
-// quarter of the workgroups (one or two per CU) keep HBM just as busy (2 tiles x 32 KB in flight per workgroup), the
+// quarter of the workgroups (one or two per CU) keep HBM just as busy (one 32 KB tile in flight per workgroup), the
 // bubbles overlap with streaming, and the other slots are free for the latency-bound Route workgroups.
 //
 // Numerics are those of refine_scan_block: each lane walks ITS row in dimension order in fp64 (QSI:364-372), the top-K
@@ -479,13 +479,13 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     const int slot_row = wave * 64 + lane / VPR;          // + i * (64 / VPR): row of this lane's i-th 16-byte slot
     const int slot_col = (lane % VPR) * VN;               // column of the slot inside a tile
 
-    // ---- issue side: position (unit, tile) two tiles ahead of the consume side -----------------------------------
+    // ---- issue side: position (unit, tile) one tile ahead of the consume side -----------------------------------
     int64_t iu = wg;                                       // unit being requested
     int it = 0;                                            // its next tile
     // Every load of the stream is UNCONDITIONAL (a slot without a row — beyond the block's rows, an id outside the store,
     // a column beyond d in a partial last tile — re-reads a row / column that exists and its data is never used): with
     // predicated loads the compiler waits for ALL outstanding loads at every tile instead of only the older register set,
-    // and the two-tile prefetch is gone (measured: 4.7 us per tile instead of ~1.3).
+    // and the prefetch is gone (measured: 4.7 us per tile instead of ~1.3).
     int32_t isrc[GATHER ? VPR : 1];                        // gather: store row of each slot for unit iu (clamped into the store)
     int irows = 1;                                         // dense: rows of unit iu that exist in the block
     // unit -> (query, first row): no division at all for one chunk per query, a 32-bit one otherwise (the launcher keeps
@@ -567,17 +567,20 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
 #endif
     bool first_unit = true; (void)first_unit;
     RS_STAMP(0);
-    V regA[VPR], regB[VPR];
+    // ONE tile in flight per wave (requested before the previous one is consumed).  Two were in flight until round 3: the same
+    // bandwidth alone (a pure-load kernel reads 6.2-6.3 TB/s either way, tools/ubench/scan_pattern.hip), but 64 MB of queued
+    // requests in front of the memory channels instead of 32 — every access of a kernel running BESIDE the scan (Route's chain of
+    // dependent reads) waited behind them.  Same-box A/B: step 46.6 -> 45.2 us, the scan alone 27.4 -> 26.4 us (and 30 registers less).
+    V regA[VPR];
     FSP_STREAM_ISSUE(regA);
-    FSP_STREAM_ISSUE(regB);
     RS_STAMP(1);
     if constexpr (FixFn::enabled) {
-        // The first two tiles are under way; now look at the counts of this workgroup's queries (one 256-row chunk per query
+        // The first tile is under way; now look at the counts of this workgroup's queries (one 256-row chunk per query
         // here: unit == query).  PENDING = handed over by the bounded select: finish its Route with the full select first —
         // rare, so the stream simply starts again afterwards (the tiles requested above are dropped: nothing of them is live
         // across the full select, which needs the registers).
         // (the counts through the CONSTANT address space: scalar loads, which do not queue behind the tile loads just issued — as
-        // vector loads they waited for both tiles; the Route launch that wrote them finished before this kernel started)
+        // vector loads they waited for the tile; the Route launch that wrote them finished before this kernel started)
         typedef const int32_t __attribute__((address_space(4)))* const_cnt_t;
         const const_cnt_t cc = (const_cnt_t)a.cand_count;
         bool any = false;
@@ -590,7 +593,6 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
             load_sources(iu);
             if constexpr (!GATHER) irsrc = unit_rsrc();
             FSP_STREAM_ISSUE(regA);
-            FSP_STREAM_ISSUE(regB);
         }
     }
 
@@ -648,19 +650,12 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
             }                                                                                                       \
         } while (0)
 
-        // tiles of this unit, two per trip: the register sets alternate along the whole stream (A, B, A, B, ...)
-        for (int t = 0; t < ntile; t += 2) {
+        // tiles of this unit; the load of the NEXT tile of the stream (this unit's or the next unit's) is issued inside
+        // FSP_STREAM_TILE, right after this one has been written to LDS
+        for (int t = 0; t < ntile; t++) {
             FSP_STREAM_TILE(regA, t * DC);
             if (t == 0) RS_STAMP(2);
-            if (t + 1 < ntile) {
-                FSP_STREAM_TILE(regB, (t + 1) * DC);
-                if (t == 0) RS_STAMP(3);
-            } else {
-                // odd tile count (d not a multiple of 2 DC; none of the BASELINE shapes): the next unit's first tile sits in
-                // set B and its second in set A — exchange them (waits for those loads: correct, just not overlapped)
-#pragma unroll
-                for (int i = 0; i < VPR; i++) { const V tmp = regA[i]; regA[i] = regB[i]; regB[i] = tmp; }
-            }
+            if (t == 1) RS_STAMP(3);
         }
         RS_STAMP(4);
         if constexpr (kSumTellsFinite) ok = __builtin_isfinite(s);

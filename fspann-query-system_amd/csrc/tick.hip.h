@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kTickThreads, 4) void tick_kernel(const TickHead h,
             cnt = __hip_atomic_load(const_cast<int32_t*>(ref.cand_count) + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // not through a stale cache line
         }
 #endif
-        // dense blocks: the streaming scan's per-unit code (buffer loads, two tiles in flight, nt policy) with one unit per
+        // dense blocks: the streaming scan's per-unit code (buffer loads, one tile in flight, nt policy) with one unit per
         // workgroup; the store gather keeps the scan block
         if constexpr (!GATHER) refine_stream_run<float, float, 32, false>(ref, smem, qi, static_cast<int64_t>(h.n_refine), h.nq_refine, true);
         else refine_scan_block<float, float, 32, true, GATHER>(ref, smem, idx, cnt);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kTickThreads, (kEnt <= 512 ? 6 : 4)) void front_ker
 
 // The stand-alone streaming scan (refine_stream_kernel) for a batch whose Route ran with a hand-over buffer: every workgroup
 // finishes the Route of the PENDING queries among ITS units with the full select (normally none: one count load per unit,
-// looked at while the first two tiles are already under way), then streams.  One 256-row chunk per query only (host: nchunks == 1), so a query's F_q is read by the workgroup that
+// looked at while the first tile is already under way), then streams.  One 256-row chunk per query only (host: nchunks == 1), so a query's F_q is read by the workgroup that
 // completed it.  This is what removes the hand-back launch from a serving loop that runs Route and Refine as separate launches.
 struct RefineRouteFix {
     static constexpr bool enabled = true;
