@@ -93,6 +93,28 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void pat(const char* __restrict__ 
             for (int i = 0; i < 32; i++) a[i] = LD(base + (size_t)wave * 32768 + (size_t)i * 1024 + lane * 16);
 #pragma unroll
             for (int i = 0; i < 32; i++) acc ^= a[i];
+        } else if (MODE == 9 || MODE == 10) {   // seg64: a wave-instruction = 16 rows x 64 B; 8 passes of 4 loads, MODE 9: one pass in flight, MODE 10: two
+            auto addr = [&](int c, int i) { const int v = lane + i * 64; return base + (size_t)(wave * 64 + v / 4) * 512 + c * 64 + (v % 4) * 16; };
+            u4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = LD(addr(0, i));
+            if (MODE == 10) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) b[i] = LD(addr(1, i));
+            }
+            for (int c = 0; c < 8; c += 2) {
+                if (MODE == 9) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { b[i] = LD(addr(c + 1, i)); acc ^= a[i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { if (c + 2 < 8) a[i] = LD(addr(c + 2, i)); acc ^= b[i]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { acc ^= a[i]; if (c + 2 < 8) a[i] = LD(addr(c + 2, i)); }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { acc ^= b[i]; if (c + 3 < 8) b[i] = LD(addr(c + 3, i)); }
+                }
+            }
         } else if (MODE >= 6) {     // seg128 as MODE 0, every pass staged through LDS like the scan: 16-byte writes into a row-major
                                     // tile (pitch 144 B), wave sync, every lane reads ITS row back.  MODE 7: + the fp64 chain
                                     // s += (q - x)^2 (q wave-uniform).  MODE 8: + an epilogue of two workgroup barriers, an LDS
@@ -187,6 +209,9 @@ int main(int argc, char** argv) {
     run("seg128 + LDS staging 4/CU", pat<6, 4>, 1024);
     run("seg128 + LDS staging + fp64 chain 4/CU", pat<7, 4>, 1024);
     run("seg128 + LDS + fp64 + epilogue 4/CU", pat<8, 4>, 1024);
+    run("seg64 (16 rows x 64 B per instr) 1 pass in flight 4/CU", pat<9, 4>, 1024);
+    run("seg64 2 passes in flight 4/CU", pat<10, 4>, 1024);
+    run("seg64 1 pass in flight, 6/CU (grid 1024)", pat<9, 6>, 1024);
     run("seg128 2 passes in flight (again)", pat<0, 4>, 1024);
     run("seg128 1 pass in flight 4/CU", pat<4, 4>, 1024);
     run("seg256 both passes up front 2/CU", pat<1, 2>, 1024);
