@@ -278,7 +278,10 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
     const int W = prm.W, P = prm.P;
     const int nd = 2 * P - 1;
     act = act && tb.nparts > 0;
-    const int gshift = grp_in_wave * G;
+    // G is a power of two (both callers): shifts instead of divisions by a run-time value — a 32-bit division is ~25 vector
+    // instructions, and the two segment lengths of every search round were a sixth of the bounded select's probe phase
+    const int lgG = 31 - __clz(G);
+    const int gshift = grp_in_wave << lgG;
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gshift);
     // GreedyPartitioner.computeKey: code bit i -> key bit 62-i (i < 63)
     const int64_t qKey = act ? static_cast<int64_t>(__brevll(qc[0]) >> 1) : 0;
@@ -300,16 +303,17 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
     // dropped: the brackets are rarely that narrow — LSH keys are skewed — and its 14 extra registers per lane were the
     // register peak of the bounded select.)
     while (__any((hiA > loA) || (hiE > loE))) {
-        const int stA = (hiA - loA + G - 1) / G, stE = (hiE - loE + G - 1) / G;
+        const int stA = (hiA - loA + G - 1) >> lgG, stE = (hiE - loE + G - 1) >> lgG;
         const int sA = loA + gl * stA, sE = loE + gl * stE;  // my segment starts
         bool pA = false, pE = false;
-        if (hiA > loA && sA < hiA) pA = recs[static_cast<int64_t>(min(sA + stA, hiA) - 1) * RW + 1] >= qKey;
-        if (hiE > loE && sE < hiE) pE = recs[static_cast<int64_t>(min(sE + stE, hiE) - 1) * RW] > qKey;
+        // (32-bit record offsets: a table holds < 2^31 / rec_words partitions)
+        if (hiA > loA && sA < hiA) pA = recs[(min(sA + stA, hiA) - 1) * RW + 1] >= qKey;
+        if (hiE > loE && sE < hiE) pE = recs[(min(sE + stE, hiE) - 1) * RW] > qKey;
         const unsigned long long bA = __ballot(pA) & gmask, bE = __ballot(pE) & gmask;
         if (hiA > loA) {
             if (bA == 0) loA = hiA;
             else {
-                const int f = (__ffsll(static_cast<long long>(bA)) - 1) - grp_in_wave * G;
+                const int f = (__ffsll(static_cast<long long>(bA)) - 1) - gshift;
                 const int nlo = loA + f * stA;
                 hiA = min(nlo + stA, hiA) - 1;
                 loA = nlo;
@@ -318,7 +322,7 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
         if (hiE > loE) {
             if (bE == 0) loE = hiE;
             else {
-                const int f = (__ffsll(static_cast<long long>(bE)) - 1) - grp_in_wave * G;
+                const int f = (__ffsll(static_cast<long long>(bE)) - 1) - gshift;
                 const int nlo = loE + f * stE;
                 hiE = min(nlo + stE, hiE) - 1;
                 loE = nlo;
@@ -343,8 +347,8 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
             if (lo <= 0) center = 0;
             else if (lo >= tb.nparts) center = tb.nparts - 1;
             else {
-                const int64_t lmax = recs[static_cast<int64_t>(lo - 1) * RW + 1];
-                const int64_t rmin = recs[static_cast<int64_t>(lo) * RW];
+                const int64_t lmax = recs[(lo - 1) * RW + 1];
+                const int64_t rmin = recs[lo * RW];
                 const int64_t dl = qKey - lmax, dr = rmin - qKey;  // distanceToRange
                 center = (dl <= dr) ? (lo - 1) : lo;
             }
@@ -354,7 +358,7 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
             const int part = center - (P - 1) + l;
             int dd = 0, b0 = 0, sz = 0;
             if (part >= 0 && part < tb.nparts) {
-                const int64_t* rec = recs + static_cast<int64_t>(part) * RW;
+                const int64_t* rec = recs + part * RW;
                 dd = ham_words(qc, reinterpret_cast<const uint64_t*>(rec + 2), W);
                 const int64_t os = rec[2 + W];
                 b0 = static_cast<int32_t>(os);
@@ -375,9 +379,10 @@ __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams 
     const int lane = tid & 63;
     const int TD = prm.TD, W = prm.W, P = prm.P;
     const int nd = 2 * P - 1;
-    const int gpb = kProbeThreads / G;                 // groups per block
-    const int grp_in_wave = lane / G, gl = lane - grp_in_wave * G;
-    const int grp_in_block = tid / G;
+    const int gpb = kProbeThreads / G;                 // groups per block (G: a power of two)
+    const int lgG = 31 - __clz(G);
+    const int grp_in_wave = lane >> lgG, gl = lane & (G - 1);
+    const int grp_in_block = tid >> lgG;
     int32_t* w3 = reinterpret_cast<int32_t*>(smem) + static_cast<size_t>(grp_in_block) * nd * 3;  // [nd][3]
 
     const int64_t item = static_cast<int64_t>(blockIdx.x) * gpb + grp_in_block;  // (q, td) flattened

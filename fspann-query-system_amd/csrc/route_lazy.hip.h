@@ -44,7 +44,7 @@ constexpr size_t lz_lds_bytes(int kEnt, int TD, int P) {         // dynamic LDS 
     return static_cast<size_t>(lz_ht_size(kEnt)) * 8 + static_cast<size_t>(TD) * P * 16 + static_cast<size_t>(kEnt) * 4 + 4096 +
            (static_cast<size_t>(TD) * P + 2) * 8 + (static_cast<size_t>(TD) * P + 1) * 4 + 8 + static_cast<size_t>(TD) * 8 +
            ((static_cast<size_t>(TD) * P * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kEnt) * 2 * 3 + static_cast<size_t>(kEnt) * 4 +
-           static_cast<size_t>(TD) * 4 + 16;
+           static_cast<size_t>(TD) * P * 8 + static_cast<size_t>(TD) * 4 + 16;
 }
 // probed partitions in flight per wave (lz_stage_u) and partitions of the crossing level one wave keeps in registers (lz_keep).
 // (Halving both fits the small class into 64 registers = 8 workgroups per CU, but a lone launch then takes 52 us instead of 42
@@ -114,6 +114,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     int32_t* pcs = reinterpret_cast<int32_t*>(smem + o);         o += (static_cast<size_t>(TP) + 1) * 4;
     o = (o + 7) & ~size_t(7);
     int64_t* ids_base = reinterpret_cast<int64_t*>(smem + o);    o += static_cast<size_t>(TD) * 8;
+    int64_t* pbase = reinterpret_cast<int64_t*>(smem + o);       o += static_cast<size_t>(TP) * 8;   // per probed partition: position of its first id in ids_bk
     uint16_t* ord = reinterpret_cast<uint16_t*>(smem + o);       o += (static_cast<size_t>(TP) * 2 + 3) & ~size_t(3);
     uint16_t* ulist = reinterpret_cast<uint16_t*>(smem + o);     o += static_cast<size_t>(kLzEntries) * 2;   // hash slots of the entries
     uint16_t* rk = reinterpret_cast<uint16_t*>(smem + o);        o += static_cast<size_t>(kEnt) * 2;   // entries per (score, bucket) rank: > 1 = collision
@@ -134,6 +135,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
     for (int i = tid; i < kLzHtSize; i += nthreads) ht[i] = kLzEmpty;
     if (block_id == 0 && tid == 0) *prm.ovf_next = 0;   // the other counter, for the next call (stream-ordered after this one)
+    __syncthreads();                                    // ids_base is read when the first query's probe list is completed
 
     // is `id` already an entry?  (an entry of an earlier level: its score is lower, this occurrence changes nothing)
     auto present = [&](int32_t id) -> bool {
@@ -189,7 +191,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
                     const int pi_ = ord[rr_];                                                                         \
                     const int4 pr_ = plist[pi_];                                                                      \
                     scv_[v_] = pr_.y;                                                                                 \
-                    if (pos_ < pr_.w) entv_[v_] = prm.ids_bk[ids_base[pi_ / P] + pr_.z + pos_];                       \
+                    if (pos_ < pr_.w) entv_[v_] = prm.ids_bk[pbase[pi_] + pos_];                                      \
                 }                                                                                                     \
             }                                                                                                         \
             _Pragma("unroll") for (int v_ = 0; v_ < kLzStageU; v_++) {                                                \
@@ -223,8 +225,8 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         // ---- probe list of this query; unused steps get an impossible partition and sort last ------------------
         if (prm.probe_G > 0) {
             // fused probe (route_probe_table): one group of G lanes per table, all tables of the query side by side
-            const int G = prm.probe_G, ngroups = nthreads / G;
-            const int grp_in_wave = lane / G, gl = lane - grp_in_wave * G, grp = tid / G;
+            const int G = prm.probe_G, lgG = 31 - __clz(G), ngroups = nthreads >> lgG;      // G: a power of two
+            const int grp_in_wave = lane >> lgG, gl = lane & (G - 1), grp = tid >> lgG;
             int32_t* w3 = reinterpret_cast<int32_t*>(pre) + grp * (2 * P - 1) * 3;     // `pre` is free until the rank pass
             for (int t0 = 0; t0 < TD; t0 += ngroups) {                                 // block-uniform trip count
                 const int td = t0 + grp;
@@ -240,6 +242,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
                 int4 e = make_int4(-1, 0x7FFF, 0, 0);
                 if (step < nprobe_l[td]) e = plist[i];
                 plist[i] = e;
+                pbase[i] = ids_base[td] + e.z;      // (a division by P per tuple trip otherwise: the table of a probe is i / P)
                 pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
             }
         } else {
@@ -248,6 +251,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
                 int4 e = make_int4(-1, 0x7FFF, 0, 0);
                 if (step < nprobe_in[qi * TD + td]) e = probe_in[qi * TP + i];
                 plist[i] = e;
+                pbase[i] = ids_base[td] + e.z;
                 pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
             }
         }
@@ -333,7 +337,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
                             const int pi = ord[rb0 + pidx];
                             const int4 pr = plist[pi];
                             if (pos < pr.w) {
-                                const uint64_t ent = prm.ids_bk[ids_base[pi / P] + pr.z + pos];
+                                const uint64_t ent = prm.ids_bk[pbase[pi] + pos];
                                 idr[k] = static_cast<int32_t>(ent >> 32);
                                 bfr[k] = static_cast<uint32_t>(ent) | ((L < 64 && pos == L - 1 && pr.w > L) ? 0x80000000u : 0u);
                             }

@@ -6,6 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
+if os.environ.get('AB_LIB'): pkg._native._SO = os.path.abspath(os.environ['AB_LIB'])   # a variant build (dev experiments)
 n, d, T, m, B, Q, k = int(os.environ.get("N", "1000000")), 128, 16, 16, 256, 1024, 10   # N: base vectors (working set of Route)
 rng = np.random.default_rng(1)
 X = rng.standard_normal((n, d), dtype=np.float32)
