@@ -481,7 +481,7 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
             hipLaunchKernelGGL(mk, dim3(static_cast<unsigned>(nq)), dim3(256), mlds, c->stream, partial, pcnt,
                                nchunks, k, out_ids, out_dist, out_count, scored);
         } else {
-            hipLaunchKernelGGL(refine_merge_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), 0, c->stream, partial, pcnt,
+            hipLaunchKernelGGL(refine_merge_kernel<false>, dim3(static_cast<unsigned>(nq)), dim3(256), static_cast<size_t>(nchunks) * 4 + 16, c->stream, partial, pcnt,
                                nchunks, k, out_ids, out_dist, out_count, scored);
         }
         FSP_HIP(hipGetLastError());

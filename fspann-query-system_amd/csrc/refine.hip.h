@@ -696,51 +696,61 @@ __global__ __launch_bounds__(kRefRows, (GATHER ? 2 : 4)) void refine_stream_kern
 // (key, pos) and chunks hold disjoint, increasing pos ranges, so the global rank of
 // an element is its own rank plus, per other chunk, an upper/lower bound.
 // KEYS_IN_LDS: the keys of all lists (nchunks * k * 8 bytes) and the list lengths are staged in LDS first, so the binary
-// searches — nchunks - 1 per element, ~7 dependent reads each — run at LDS latency instead of L2 latency (the shipped
-// profiles: 32 / 86 lists of 100; 215 / 516 us per 1 024 queries from global memory).  The host picks the variant by size.
+// searches run at LDS latency instead of L2 latency (the shipped profiles: 32 / 86 lists of 100).  The host picks the
+// variant by size.
+// A cut first: with j = ceil(k / nchunks), the largest j-th key over the lists has at least k keys at or below it (j from
+// every list), so only each list's PREFIX up to that key can hold a winner — ~3 k elements instead of nchunks * k, and
+// the searches run over prefixes of a few entries (SIFT_P10_HIGH: 86 lists x 100 -> ~4 per list).
 template <bool KEYS_IN_LDS>
 __global__ __launch_bounds__(256) void refine_merge_kernel(const RefinePartial* __restrict__ partial,
                                                            const int32_t* __restrict__ partial_cnt, int nchunks, int k,
                                                            int32_t* __restrict__ out_ids, double* __restrict__ out_dist,
                                                            int32_t* __restrict__ out_count, int32_t* __restrict__ scored) {
     extern __shared__ __align__(16) unsigned char merge_smem[];
-    uint64_t* s_keys = reinterpret_cast<uint64_t*>(merge_smem);                       // [nchunks][k]
-    int32_t* s_cnt = reinterpret_cast<int32_t*>(s_keys + static_cast<size_t>(nchunks) * k);   // [nchunks]
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(merge_smem);                       // [nchunks][k]            (KEYS_IN_LDS)
+    int32_t* s_pref = reinterpret_cast<int32_t*>(merge_smem + (KEYS_IN_LDS ? static_cast<size_t>(nchunks) * k * 8 : 0));   // [nchunks] prefix lengths
     const int64_t qi = blockIdx.x;
     const int tid = threadIdx.x;
     const int nelem = nchunks * k;
-    __shared__ int s_total, s_nvalid;
-    if (tid == 0) {
-        int t = 0, nv = 0;
-        for (int c = 0; c < nchunks; c++) {
-            t += partial_cnt[(qi * nchunks + c) * 2];
-            nv += partial_cnt[(qi * nchunks + c) * 2 + 1];
-        }
-        s_total = t;
-        s_nvalid = nv;
-    }
-    if constexpr (KEYS_IN_LDS) {
-        for (int c = tid; c < nchunks; c += blockDim.x) s_cnt[c] = partial_cnt[(qi * nchunks + c) * 2];
+    __shared__ int s_total, s_nvalid, s_short;
+    __shared__ unsigned long long s_cut;
+    auto key_at = [&](int c, int i) -> uint64_t { return KEYS_IN_LDS ? s_keys[c * k + i] : partial[(qi * nchunks + c) * k + i].key; };
+    if (tid == 0) { s_total = 0; s_nvalid = 0; s_short = 0; s_cut = 0ull; }
+    if constexpr (KEYS_IN_LDS)
         for (int e = tid; e < nelem; e += blockDim.x) s_keys[e] = partial[qi * nelem + e].key;     // entries beyond a list's length are never read
+    __syncthreads();
+    const int j = (k + nchunks - 1) / nchunks;
+    for (int c = tid; c < nchunks; c += blockDim.x) {
+        const int cc = partial_cnt[(qi * nchunks + c) * 2];
+        s_pref[c] = cc;                                            // the list's length until the cut is known
+        atomicAdd(&s_total, cc);
+        atomicAdd(&s_nvalid, partial_cnt[(qi * nchunks + c) * 2 + 1]);
+        if (cc < j) atomicAdd(&s_short, 1);                        // a list too short to vouch for j keys: no cut
+        else atomicMax(&s_cut, static_cast<unsigned long long>(key_at(c, j - 1)));
     }
     __syncthreads();
     const int eff = min(k, s_total);
+    if (s_short == 0) {                                            // every list holds >= j keys <= cut: >= k in all
+        const uint64_t cut = s_cut;
+        for (int c = tid; c < nchunks; c += blockDim.x) {
+            int lo = 0, hi = s_pref[c];                            // first index with key > cut
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (key_at(c, mid) <= cut) lo = mid + 1; else hi = mid; }
+            s_pref[c] = lo;
+        }
+    }
+    __syncthreads();
     for (int e = tid; e < nelem; e += blockDim.x) {
         const int c = e / k, rk = e - c * k;
-        const int cc = KEYS_IN_LDS ? s_cnt[c] : partial_cnt[(qi * nchunks + c) * 2];
-        if (rk >= cc) continue;
-        const uint64_t mykey = KEYS_IN_LDS ? s_keys[e] : partial[qi * nelem + e].key;
+        if (rk >= s_pref[c]) continue;
+        const uint64_t mykey = key_at(c, rk);
         int rank = rk;
         for (int c2 = 0; c2 < nchunks && rank < eff; c2++) {
             if (c2 == c) continue;
-            const int n2 = KEYS_IN_LDS ? s_cnt[c2] : partial_cnt[(qi * nchunks + c2) * 2];
-            const RefinePartial* lst = partial + (qi * nchunks + c2) * k;
-            const uint64_t* lk = s_keys + c2 * k;
-            // c2 < c: count keys <= me.key (earlier positions win ties); c2 > c: keys < me.key
-            int lo = 0, hi = n2;
+            // c2 < c: count keys <= mykey (earlier positions win ties); c2 > c: keys < mykey
+            int lo = 0, hi = s_pref[c2];
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                const uint64_t km = KEYS_IN_LDS ? lk[mid] : lst[mid].key;
+                const uint64_t km = key_at(c2, mid);
                 const bool before = (c2 < c) ? (km <= mykey) : (km < mykey);
                 if (before) lo = mid + 1; else hi = mid;
             }
