@@ -1014,12 +1014,16 @@ def main():
         dist.all_reduce(okf, op=dist.ReduceOp.MIN)
         if int(okf.item()) != 1:
             raise SystemExit(f"bench: rank {rank}: the gathered top-k differs from an independent all-gather of the ranks' buffers")
+        ranks_verified = True
+    else:
+        ranks_verified = None
     if rank == 0:
         out = {
             "metric": (("queries/sec @ recall@%d, SIFT-1M-shaped synthetic data d=%d B=%d" % (k, d, B)) if args.data in ("gaussian", "clustered")
                        else "queries/sec @ recall@%d, d=%d B=%d" % (k, d, B)),
             "value": round(qps, 1),
             "unit": "queries/s",
+            "all_ranks_verified": ranks_verified,   # N > 1 (or --gpus 1 under torch.distributed.run): every rank compared every slice of the gathered top-k
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
