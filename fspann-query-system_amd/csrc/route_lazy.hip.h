@@ -174,6 +174,14 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 #else
 #define LZ_STAMP(i) do { } while (0)
 #endif
+// FSPANN_LZ_STOP_AFTER=n (tools/pmc_phases.sh only, never a release build): every query stops behind phase n (1 probe, 2 probe
+// ordering, 3 level walk, 5 rank) — results are garbage, the instruction counters of the truncated kernel are what is wanted.
+#ifdef FSPANN_LZ_STOP_AFTER   /* (a plain `if`, not do { } while (0): its `continue` is the query loop's) */
+#define LZ_STOP(n) if (FSPANN_LZ_STOP_AFTER == (n) && prm.nq > 0) { __syncthreads(); if (tid == 0) prm.out_count[qi] = 0;               \
+        const int used_ = min(s_u, kLzEntries); for (int i_ = tid; i_ < used_; i_ += nthreads) ht[ulist[i_]] = kLzEmpty; __syncthreads(); continue; }
+#else
+#define LZ_STOP(n)
+#endif
 // Every live tuple of the sorted probes [RA, RB): BODY sees `id` (>= 0 when live and not deleted, else -1), its bucket
 // field `bf` and the partition's distance `sc`;
 // kLzStageU partitions are in flight per wave (one coalesced 256-byte id row each).  Trip counts are wave-uniform.
@@ -258,6 +266,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         if (tid == 0) { s_u = 0; s_R = TP; s_ncoll = 0; s_bad = 0; s_short = 0; pkv[TP] = make_uint2(0xFFFFFFFFu, 0u); }
         __syncthreads();
         LZ_STAMP(1);
+        LZ_STOP(1)
         // Register note: everything below indexes by tid / lane / wave, and the compiler would compute all of those per-thread
         // offsets ONCE before the query loop and keep them alive through the probe above (its peak: a window of key ranges,
         // codes and id ranges per lane) — enough to spill.  Redefining the three here (the asm changes nothing) ties every
@@ -285,6 +294,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         }
         __syncthreads();
         LZ_STAMP(2);
+        LZ_STOP(2)
         const int R = s_R;                           // valid probes occupy sorted positions [0, R)
         bool overflow = false;
         int r0 = 0, u = 0;
@@ -461,6 +471,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
             __syncthreads();
         }
         LZ_STAMP(3);
+        LZ_STOP(3)
         // ---- 3. rank the entries by (score, bucket) ---------------------------------------------------------------
         const int nsel = u;
         if (nsel > kLzSortMax) overflow = true;
@@ -529,6 +540,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
             }
             __syncthreads();
             LZ_STAMP(5);
+            LZ_STOP(5)
             const int ncoll = s_ncoll;
 #ifdef FSPANN_DEBUG_STAMPS
             if (tid == 0 && prm.dbg && qi == block_id) { prm.dbg[block_id * 16 + 13] = ncoll; prm.dbg[block_id * 16 + 15] = nsel; prm.dbg[block_id * 16 + 14] = dbg_outer | (dbg_inner << 8) | (dbg_reload << 16) | (static_cast<long long>(dbg_nitb) << 24); }
@@ -612,6 +624,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         __syncthreads();
         LZ_STAMP(7);
     }
+#undef LZ_STOP
 #undef LZ_STAMP
 #undef LZ_FOR_TUPLES
 #undef LZ_INSERT
