@@ -126,7 +126,15 @@ int upload_index(fspann_ctx* c) {
         }
         int bits = 1;
         while (bits < 16 && (4 << bits) < maxp) bits++;      // about four partitions per directory entry
-        bits = std::min(20, std::max(1, bits + c->knob_dir_extra_bits));
+        // ... and up to six bits more while the whole directory stays within 64 MB: keys are skewed (the most popular 12-bit prefix of
+        // BASELINE config #2 covers 1 974 of 15 625 partitions), every extra bit halves the brackets the search starts from, and a
+        // search round is a dependent load (step 44.9 -> 43.9 us at 18 bits = 33 MB; FSPANN_ROUTE_DIR_EXTRA_BITS overrides)
+        int extra = c->knob_dir_extra_bits;
+        if (extra == kDirBitsAuto) {
+            extra = 0;
+            while (extra < 6 && bits + extra + 1 <= 20 && static_cast<size_t>(TD) * ((size_t(1) << (bits + extra + 1)) + 1) * sizeof(int2) <= (size_t(64) << 20)) extra++;
+        }
+        bits = std::min(20, std::max(1, bits + extra));
         const size_t D = size_t(1) << bits;
         if (mono && maxp > 0 && static_cast<size_t>(TD) * (D + 1) < (size_t(1) << 30)) {
             dir.resize(static_cast<size_t>(TD) * (D + 1));
@@ -605,7 +613,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
         c->knob_probe_dir = env_int("FSPANN_ROUTE_DIR", 1) != 0;
         c->knob_lazy_small = env_int("FSPANN_ROUTE_LAZY_SMALL", 1) != 0;
-        c->knob_dir_extra_bits = env_int("FSPANN_ROUTE_DIR_EXTRA_BITS", 0);
+        c->knob_dir_extra_bits = env_int("FSPANN_ROUTE_DIR_EXTRA_BITS", kDirBitsAuto);   // unset: as many as fit 64 MB (at most six)
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
         c->knob_refine_stream = std::min(4, std::max(-1, env_int("FSPANN_REFINE_STREAM", -1)));   // -1: 4 per CU dense, 3 per CU gather
         c->knob_tick_refine = std::min(4, std::max(1, env_int("FSPANN_TICK_REFINE", 1)));
