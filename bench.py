@@ -144,7 +144,51 @@ def main():
                          "(latency of a single batch, nothing overlaps).  tick: one stream, three batches in flight, encode(t+2) + "
                          "Route(t+1) + Refine(t) as ONE kernel (fspann_tick_dev).  front (value): as concurrent, but a context runs the encode "
                          "of its NEXT batch and the Route of this one as ONE launch (fspann_tick_dev without a Refine part), then the scan")
+    ap.add_argument("--no-shipped", action="store_true", help="skip the reference's shipped profiles (SIFT_P4_FAST / SIFT_P10_HIGH), run as child "
+                                                              "processes after the headline workload and reported under `extra`")
+    ap.add_argument("--shipped-steps", type=int, default=40, help="timed steps of each shipped-profile child run")
+    ap.add_argument("--solo-tail", type=int, default=16, help="drained solo dispatches of the refinement scan timed AFTER the timed region "
+                                                              "(the roofline's readings do not depend on --steps)")
+    ap.add_argument("--launch-check", action="store_true", help="(tests) only prove the N-rank launch: every rank joins a gloo group, rank 0 prints one JSON line")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves — a CHILD torch.distributed.run,
+    # spawned before this process touches the GPU (no exec: replacing a process that initialised the GPU takes the box down), its
+    # stdout (rank 0's JSON line) and exit code relayed.  Never a silent one-GPU run.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("[bench] --gpus %d without a rank environment: launching %s" % (args.gpus, " ".join(cmd)))
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        proc = subprocess.run(cmd, env=env)
+        raise SystemExit(proc.returncode)
+    if args.launch_check:
+        import torch.distributed as dist
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            raise SystemExit(f"bench: WORLD_SIZE={world} but --gpus {args.gpus}")
+        if world > 1 or "RANK" in os.environ:
+            import torch
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.tensor([rank + 1], dtype=torch.int64)
+            dist.all_reduce(t)
+            ok = int(t.item()) == world * (world + 1) // 2
+            dist.destroy_process_group()
+        else:
+            ok = True
+        if os.environ.get("FSPANN_BENCH_LAUNCH_FAIL") == str(rank):
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"launch_check": bool(ok), "n_gpus": world}), flush=True)
+        raise SystemExit(0 if ok else 1)
 
     # Only the final JSON line may reach stdout: libraries (RCCL prints a version banner) write to fd 1 too.
     real_stdout = os.dup(1)
@@ -157,7 +201,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        raise SystemExit(f"bench: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to measure a different job than the one asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)
@@ -473,7 +517,7 @@ def main():
             step(mode)
         barrier()
         every = max(2, steps // max(1, min(8, steps // 40)))   # up to eight solo readings, at most one per 40 steps (a drain costs ~2 steps)
-        solo_n, solo_ms = 0, 0.0
+        solo = []
         if with_events and nact == 1:
             ctxs[0].refine_timing_begin(steps, every)
         if with_events and nact > 1:                    # overlapped readings: sampled dispatches of the other contexts, as they run
@@ -486,8 +530,7 @@ def main():
                     c_.sync()
                 ctxs[0].refine_timing_begin(2, 1)        # solo reading: everything drained, this step runs alone on context 0
                 step(mode, force_ctx=0)
-                n_, ms_ = ctxs[0].refine_timing_end()
-                solo_n, solo_ms = solo_n + n_, solo_ms + ms_
+                solo.append(ctxs[0].refine_timing_end())
             else:
                 step(mode)
         flush(nact)
@@ -504,7 +547,7 @@ def main():
         rt = None
         overlapped[0] = None
         if with_events:
-            rt = [ctxs[0].refine_timing_end()] if nact == 1 else [(solo_n, solo_ms)]
+            rt = [ctxs[0].refine_timing_end()] if nact == 1 else solo
             if nact > 1:
                 ov = [c_.refine_timing_end() for c_ in ctxs[1:nact]]
                 on = sum(x for x, _ in ov)
@@ -512,6 +555,38 @@ def main():
         active[0] = 1
         use_front[0] = False
         return el, rt, every
+
+    def solo_readings(mode, count, nact=1, front=False):
+        """`count` drained SOLO dispatches of the refinement scan, untimed (after the timed region): the pipeline is set up as in
+        timed(), a few steps bring it to its steady state, then every reading drains all contexts and runs ONE step alone on context 0
+        whose scan dispatch carries HIP start/stop events.  Consecutive readings take different batches (cold blocks).  Returns the
+        per-dispatch milliseconds."""
+        active[0] = nact
+        for b_ in bufs:
+            b_["nsteps"] = 0
+        step_no[0] = 0
+        use_front[0] = front and mode == "dense" and len(probe_passes) == 1 and not args.route_counters
+        if use_front[0]:
+            for si_, (c_, b_) in enumerate(zip(ctxs[:nact], bufs[:nact])):
+                b_["front_no"] = 0
+                c_.encode_dev(Q, q_all[si_ % NB].data_ptr(), F32, b_["fcodes"][0].data_ptr(), 0, b_["bad"].data_ptr())
+        for _ in range(2 * nact):
+            step(mode)
+        out_ms = []
+        for _ in range(count):
+            for c_ in ctxs[:nact]:
+                c_.sync()
+            ctxs[0].refine_timing_begin(2, 1)
+            step(mode, force_ctx=0)
+            ctxs[0].sync()
+            n_, ms_ = ctxs[0].refine_timing_end()
+            if n_ > 0:
+                out_ms.append(ms_ / n_)
+        flush(nact)
+        barrier()
+        active[0] = 1
+        use_front[0] = False
+        return out_ms
 
     # ---------------- the timed region ------------------------------------------------------------------------------------
     mode = args.candidates
@@ -566,8 +641,21 @@ def main():
                            note="outputs of the last step every context ran INSIDE the timed region (front_kernel + scan on its own stream), "
                                 "compared with the three-launch path on context 0 and, in the cpu_baseline leg, with the CPU oracle")
         timed_snaps = snaps
-    ref_launches = sum(x for x, _ in rt)
-    ref_ms = sum(t for _, t in rt) / max(1, ref_launches)          # kernel-attached HIP events, on the context's stream
+    # The roofline's readings must not depend on --steps (the driver's 20 steps hold ONE drained dispatch): an untimed tail of
+    # drained solo dispatches of the same scan, same pipeline, right behind the timed region (never part of `value`).
+    region_n = sum(x for x, _ in rt)
+    region_ms = sum(t for _, t in rt)
+    tail_ms = []
+    if not use_tick and args.solo_tail > 0 and not shipped:
+        tail_ms = solo_readings(mode, args.solo_tail, nact=nctx, front=args.pipeline == "front")
+    ref_launches = region_n + len(tail_ms)
+    ref_ms = (region_ms + sum(tail_ms)) / max(1, ref_launches)     # kernel-attached HIP events, on the context's stream
+    solo_stats = (dict(in_region=dict(launches=region_n, avg_launch_ms=round(region_ms / max(1, region_n), 5)),
+                       tail=dict(launches=len(tail_ms), median_ms=round(float(np.median(tail_ms)), 5), min_ms=round(min(tail_ms), 5),
+                                 max_ms=round(max(tail_ms), 5), mean_ms=round(float(np.mean(tail_ms)), 5),
+                                 note="drained solo dispatches behind the timed region (untimed): all contexts idle, one step on context 0, "
+                                      "HIP start/stop events attached to its scan dispatch; consecutive readings scan different blocks"))
+                  if tail_ms else None)
     ms_per_step = elapsed * 1000.0 / args.steps
     q_job = Qw if args.scaling == "strong" else world * Q
     qps = q_job * args.steps / elapsed
@@ -830,7 +918,7 @@ def main():
                     peak_launch_sized=peak_launch_sized,
                     frac_of_launch_sized=round(achieved / peak_launch_sized, 4) if peak_launch_sized else None,
                     traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5), launches=ref_launches,
+                    algorithmic_bytes_per_launch=ref_bytes, avg_launch_ms=round(ref_ms, 5), launches=ref_launches, solo=solo_stats,
                     working_set_bytes=(NB * Q * B * d * 4) if mode == "dense" else n * d * 4,
                     timing=("every %d-th step of the timed region runs its three stages as stand-alone kernels instead of the shared one; the "
                             "refinement-scan dispatch of those steps carries HIP start/stop events (hipExtLaunchKernel, on the context's stream)"

@@ -189,7 +189,7 @@ int upload_index(fspann_ctx* c) {
     //   inv[td][id]  position of id in table td's id list (a table holding an id twice cannot be inverted: select stays off)
     //   ids_bk       every partition's ids once more, as (id << 32 | bucket field at the initial HashMap capacity),
     //                sorted by bucket within the partition, so the ids with the smallest buckets are a prefix
-    free_devt(c->d_inv); free_devt(c->d_ids_bk);
+    free_devt(c->d_inv); free_devt(c->d_ids_bk); free_devt(c->d_bin16);
     c->bk_epoch = -1;
     if (c->n_ids > 0 && static_cast<int64_t>(TD) * c->n_ids < (1LL << 33) && c->cap0 <= (1 << kBucketBits) && c->cfg.block_size <= 4096) {
         std::vector<int32_t> inv(static_cast<size_t>(TD) * static_cast<size_t>(c->n_ids), -1);
@@ -230,7 +230,42 @@ int upload_index(fspann_ctx* c) {
               } catch (...) { ok = false; }   // out of host memory: the bounded select stays off
             });
         for (auto& t : th) t.join();
+        // bin16: the HashMap bin (table length cap0 <= 65536) of every id in partition order, one padded row of 1 << bin16_shift
+        // entries per partition — the bounded select's exact treeify check counts ALL ids of the probed partitions per bin with
+        // it (route_lazy.hip.h, step 0).  Built when that check can be asked for: opaque ids (caller-supplied hashCodes), or forced.
+        const bool want_bin16 = (c->knob_bincheck == 1) || (c->knob_bincheck < 0 && !c->decimal_ids);
+        std::vector<uint16_t> b16;
+        int b16_shift = 0;
+        if (ok && want_bin16 && c->cap0 <= 65536 && parts > 0) {
+            int64_t maxsz = 4;
+            for (int td = 0; td < TD; td++)
+                for (int p = 0; p < c->h_tables[td].nparts; p++) maxsz = std::max<int64_t>(maxsz, c->h_off[td][p + 1] - c->h_off[td][p]);
+            while ((int64_t(1) << b16_shift) < maxsz) b16_shift++;
+            if (b16_shift <= 12 && (static_cast<uint64_t>(parts) << b16_shift) < (uint64_t(1) << 33)) {
+                try {
+                    b16.assign(static_cast<size_t>(parts) << b16_shift, 0xFFFFu);
+                    for (int td = 0; td < TD; td++) {
+                        const RouteTable& t = c->h_tables[td];
+                        const std::vector<int32_t>& v = c->h_ids[td];
+                        for (int p = 0; p < t.nparts; p++) {
+                            uint16_t* row = b16.data() + (static_cast<size_t>(t.part_base + p) << b16_shift);
+                            const int64_t b0 = c->h_off[td][p], b1 = c->h_off[td][p + 1];
+                            for (int64_t i = b0; i < b1; i++) {
+                                uint32_t h = static_cast<uint32_t>(c->h_java_hash[static_cast<size_t>(v[i])]);
+                                h ^= (h >> 16);   // HashMap.hash()
+                                row[i - b0] = static_cast<uint16_t>(h & bmask);
+                            }
+                        }
+                    }
+                } catch (...) { b16.clear(); }   // out of host memory: no check -> the bounded select stays off for opaque ids
+            }
+        }
         if (ok) {
+            if (!b16.empty()) {
+                FSP_HIP(hipMalloc(&c->d_bin16, b16.size() * 2 + 64));
+                FSP_HIP(hipMemcpy(c->d_bin16, b16.data(), b16.size() * 2, hipMemcpyHostToDevice));
+                c->bin16_shift = b16_shift;
+            }
             FSP_HIP(hipMalloc(&c->d_inv, inv.size() * 4));
             FSP_HIP(hipMemcpy(c->d_inv, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
             FSP_HIP(hipMalloc(&c->d_ids_bk, bk.size() * 8));
@@ -318,6 +353,7 @@ struct RoutePlan {
     int lds_sort_words;
     bool long_lists;
     int lazy, lazy_cap, lz_ht_size, lz_grid, lz_entries;
+    bool bincheck;                 // the bounded select runs its exact treeify check (bin16)
     size_t lz_lds_bytes, small_bytes;
 };
 
@@ -385,12 +421,21 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
     // ---- bounded select: legal when the first `limit` entries do not depend on how many ids exist ----------------
     pl.lazy = 0;
     const bool cap_fixed = java_final_cap_host(c->cap0, mt) == c->cap0;       // HashMap never resizes
-    const bool legal = c->d_inv && c->d_ids_bk && c->bk_epoch == c->meta_epoch && !pl.need_cap && cap_fixed && !want_counters && limit <= (for_tick ? 512 : 1024) && pl.lds_mode;
+    // ... and a treeified bin of bestScore (nine distinct ids in one bin, PIS:619 + HashMap.TREEIFY_THRESHOLD) cannot go unnoticed: the
+    // bounded select loads only the partitions that decide the first `limit` entries, so a bin that fills through ids it never loads
+    // is seen only by its exact check over bin16 (route_lazy.hip.h, step 0).  Opaque ids (caller-supplied String.hashCode) always run
+    // it; decimal ordinals — whose hashCodes spread ~4 500 ids over 32 768 bins like random draws, nine in one bin ~2e-9 per query —
+    // run it when FSPANN_ROUTE_BINCHECK=1 asks for it.  No bin16 where it is needed: the full select.
+    pl.bincheck = (c->knob_bincheck == 1) || (c->knob_bincheck < 0 && !c->decimal_ids);
+    const bool check_ok = !pl.bincheck || c->d_bin16 != nullptr;
+    const bool legal = c->d_inv && c->d_ids_bk && c->bk_epoch == c->meta_epoch && !pl.need_cap && cap_fixed && !want_counters && limit <= (for_tick ? 512 : 1024) && pl.lds_mode && check_ok;
     if (legal && c->route_mode != 1 && (c->route_mode == 2 || static_cast<int64_t>(limit) * 4 <= mt)) {
         const int cap_env = c->knob_lazy_cap;   // tests: distinct ids one query may hold before it is handed back
         // size class: 512 entries (19.6 KB, 6 workgroups per CU) when limit <= 256 and the probe's scratch fits the smaller key
         // array; the tick kernel keeps the large class (its redo runs the full select over the same LDS)
-        const bool small_cls = c->knob_lazy_small && !for_tick && limit <= 256 && (kLzThreads / 16) * (2 * pl.P - 1) * 12 <= 512 * 4;
+        // (the 512-entry kernel is built WITHOUT the exact treeify check: its loads live across the ordering step and would spill at 80
+        // registers — and any scratch use costs every dispatch of the stream; a checked Route takes the 1024-entry class, 4 per CU)
+        const bool small_cls = c->knob_lazy_small && !for_tick && !pl.bincheck && limit <= 256 && (kLzThreads / 16) * (2 * pl.P - 1) * 12 <= 512 * 4;
         const int kent = small_cls ? 512 : (limit <= 512 ? kLzEntriesMax : 2048);
         const size_t lds = lz_lds_bytes(kent, c->TD, pl.P);
         if (TP < 32768 && lds <= budget && (small <= lds || !for_tick)) {   // small <= lds: a handed-over query runs the full select over this LDS
@@ -613,6 +658,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_fused_probe = env_int("FSPANN_ROUTE_FUSED_PROBE", 1) != 0;
         c->knob_probe_dir = env_int("FSPANN_ROUTE_DIR", 1) != 0;
         c->knob_lazy_small = env_int("FSPANN_ROUTE_LAZY_SMALL", 1) != 0;
+        c->knob_bincheck = env_int("FSPANN_ROUTE_BINCHECK", -1);
         c->knob_dir_extra_bits = env_int("FSPANN_ROUTE_DIR_EXTRA_BITS", kDirBitsAuto);   // unset: as many as fit 64 MB (at most six)
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
         c->knob_refine_stream = std::min(4, std::max(-1, env_int("FSPANN_REFINE_STREAM", -1)));   // -1: 4 per CU dense, 3 per CU gather
@@ -655,7 +701,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     }
     if (parent) {                                   // a clone owns none of the shared arrays
         c->d_alphaT = nullptr; c->d_r = nullptr; c->d_omega = nullptr; c->d_alphaT32 = nullptr;
-        c->d_tables = nullptr; c->d_recs = nullptr; c->d_ids = nullptr; c->d_dir = nullptr; c->d_inv = nullptr; c->d_ids_bk = nullptr;
+        c->d_tables = nullptr; c->d_recs = nullptr; c->d_ids = nullptr; c->d_dir = nullptr; c->d_inv = nullptr; c->d_ids_bk = nullptr; c->d_bin16 = nullptr;
         c->d_java_hash = nullptr; c->d_deleted_bits = nullptr;
         if (!c->store_owned) c->d_store = nullptr;
     }
@@ -665,7 +711,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     if (uint32_t* db = c->d_deleted_bits.exchange(nullptr)) (void)hipFree(db);
     if (c->store_owned) free_dev(c->d_store);
     free_dev(c->ws_tickfix.p); free_dev(c->d_fixparams); free_dev(c->ws_gt.p); free_dev(c->bld_codes.p);
-    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk);
+    free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk); free_devt(c->d_bin16);
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -697,7 +743,7 @@ int fspann_ctx_clone(fspann_ctx* src, fspann_ctx** out) {
     c->h_tables = root->h_tables;
     c->h_table_set.assign(c->TD, 1);
     c->d_tables = root->d_tables; c->d_recs = root->d_recs; c->rec_words = root->rec_words; c->d_dir = root->d_dir; c->dir_bits = root->dir_bits;
-    c->d_ids = root->d_ids; c->d_inv = root->d_inv; c->d_ids_bk = root->d_ids_bk;
+    c->d_ids = root->d_ids; c->d_inv = root->d_inv; c->d_ids_bk = root->d_ids_bk; c->d_bin16 = root->d_bin16; c->bin16_shift = root->bin16_shift;
     c->meta_epoch = root->meta_epoch; c->bk_epoch = root->bk_epoch; c->route_mode = src->route_mode;
     c->total_parts = root->total_parts; c->total_ids = root->total_ids;
     c->n_ids = root->n_ids; c->d_java_hash = root->d_java_hash; c->decimal_ids = root->decimal_ids;   // (deleted bits: read from the owner at every call)
@@ -1167,6 +1213,7 @@ int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int prob
         // (tick: the full select of PENDING queries) leave the turn alone, or the next call would start on a counter
         // nobody zeroed and hand its full select a list with another batch's queries in front.
         if (launches_lazy) c->ovf_flip ^= 1;
+        p.bin16 = pl.bincheck ? c->d_bin16 : nullptr; p.bin16_shift = c->bin16_shift;
         p.inv = c->d_inv; p.ids_bk = c->d_ids_bk; p.n_ids = c->n_ids; p.lazy_cap = pl.lazy_cap; p.lz_ht_size = pl.lz_ht_size;
         p.lz_ht_shift = 32 - __builtin_ctz(pl.lz_ht_size);
         p.ovf_count = static_cast<int32_t*>(c->ws_ovf.p) + 16 * c->ovf_flip;          // this call's counter ...
@@ -1226,16 +1273,16 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     c->last_route_lazy = pl.lazy;
     if (pl.lazy) {
         if (pl.lz_entries == 512) {
-            hipLaunchKernelGGL((route_select_lazy_kernel<kLzThreads, 512>), dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
+            hipLaunchKernelGGL((route_select_lazy_kernel<kLzThreads, 512, false>), dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
         } else if (pl.lz_entries == 2048) {
-            auto lk = route_select_lazy_kernel<kLzThreads, 2048>;
+            auto lk = route_select_lazy_kernel<kLzThreads, 2048, true>;
             if (!(c->attr_mask & 1024u)) {
                 FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
                 c->attr_mask |= 1024u;
             }
             hipLaunchKernelGGL(lk, dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
         } else {
-            auto lk = route_select_lazy_kernel<kLzThreads, kLzEntriesMax>;
+            auto lk = route_select_lazy_kernel<kLzThreads, kLzEntriesMax, true>;
             if (!(c->attr_mask & 16u)) {
                 FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
                 c->attr_mask |= 16u;
@@ -1706,9 +1753,9 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
     };
     if (front && (plR.lz_entries == 512 || plR.lz_entries == kLzEntriesMax)) {
         if (plR.lz_entries == 512) {
-            hipLaunchKernelGGL(front_kernel<512>, dim3(static_cast<unsigned>(total)), dim3(kTickThreads), lds, c->stream, p, eaT, routeT);
+            hipLaunchKernelGGL((front_kernel<512, false>), dim3(static_cast<unsigned>(total)), dim3(kTickThreads), lds, c->stream, p, eaT, routeT);
         } else {
-            auto fk = front_kernel<kLzEntriesMax>;
+            auto fk = front_kernel<kLzEntriesMax, true>;
             if (!(c->attr_mask & 2048u)) {
                 FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
                 c->attr_mask |= 2048u;

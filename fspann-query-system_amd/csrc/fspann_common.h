@@ -101,6 +101,7 @@ struct fspann_ctx {
     int knob_wave_sort = 1;          // FSPANN_ROUTE_WAVE_SORT=0: long lists' groups are sorted by the whole workgroup one by one (dev A/B)
     int knob_tick_fuse = 1;          // FSPANN_TICK_FUSE=0: fspann_tick_dev always uses the stand-alone kernels
     int knob_tick_front = 100;       // FSPANN_TICK_FRONT: percent of a tick's Route workgroups that head the grid
+    int knob_bincheck = -1;          // FSPANN_ROUTE_BINCHECK: the bounded select's exact treeify check (-1: on for opaque ids, off for decimal ordinals; 0 / 1 force)
     int last_tick_fused = 0;
 
     // GFunctions: alphaT[dim][P_total] fp64 (transposed for coalescing), r/omega[P_total]
@@ -130,6 +131,8 @@ struct fspann_ctx {
     int32_t* d_ids = nullptr;
     int32_t* d_inv = nullptr;        // [TD][n_ids] inverse id map for the bounded select (null: a table holds an id twice)
     uint64_t* d_ids_bk = nullptr;    // per partition: (id << 32 | bucket field) sorted by bucket, for the bounded select
+    uint16_t* d_bin16 = nullptr;     // [total_parts][1 << bin16_shift] HashMap bin (at cap0) of every id, partition order, padded per partition:
+    int bin16_shift = 0;             //   what the bounded select's exact treeify check reads (one 128-byte line per 64-id partition)
     int meta_epoch = 0, bk_epoch = -1;  // d_ids_bk / d_inv are valid for the id metadata of bk_epoch
     int route_mode = 0;              // 0 auto, 1 always route_select_kernel, 2 bounded select whenever its preconditions hold
     fspann::DevBuf ws_ovf;

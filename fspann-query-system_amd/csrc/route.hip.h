@@ -75,6 +75,8 @@ struct RouteParams {
     const int32_t* inv;            // [TD][n_ids] position of an id in table td's id list (-1 = absent)
     const uint64_t* ids_bk;        // ids of every partition as (id << 32 | bucket field), bucket-sorted within the partition
     int64_t n_ids;
+    const uint16_t* bin16;         // [parts][1 << bin16_shift] HashMap bin of every id, partition order (null: no exact treeify check)
+    int bin16_shift;
     int lazy_cap;                  // tuples one query may insert before it is handed to route_select_kernel
     int lz_ht_size, lz_ht_shift;
     int32_t* ovf_next;             // the OTHER overflow counter: zeroed by the lazy kernel for the next call (ping-pong)

@@ -44,7 +44,7 @@ constexpr size_t lz_lds_bytes(int kEnt, int TD, int P) {         // dynamic LDS 
     return static_cast<size_t>(lz_ht_size(kEnt)) * 8 + static_cast<size_t>(TD) * P * 16 + static_cast<size_t>(kEnt) * 4 + 4096 +
            (static_cast<size_t>(TD) * P + 2) * 8 + (static_cast<size_t>(TD) * P + 1) * 4 + 8 + static_cast<size_t>(TD) * 8 +
            ((static_cast<size_t>(TD) * P * 2 + 3) & ~size_t(3)) + static_cast<size_t>(kEnt) * 2 * 3 + static_cast<size_t>(kEnt) * 4 +
-           static_cast<size_t>(TD) * P * 8 + static_cast<size_t>(TD) * 4 + 16;
+           static_cast<size_t>(TD) * P * 8 + static_cast<size_t>(TD) * 4 + 16 + static_cast<size_t>(TD) * 4 + static_cast<size_t>(TD) * P * 4;
 }
 // probed partitions in flight per wave (lz_stage_u) and partitions of the crossing level one wave keeps in registers (lz_keep).
 // (Halving both fits the small class into 64 registers = 8 workgroups per CU, but a lone launch then takes 52 us instead of 42
@@ -90,7 +90,10 @@ __device__ __forceinline__ int wave_cut1024(const int32_t* bins, int need, int l
 // The bounded select of the queries q_first, q_first + q_stride, ... < prm.nq by ONE workgroup of kThreads threads
 // (`smem` = its dynamic LDS, `block_id` = its slice of the global fallback arena).  Called by route_select_lazy_kernel
 // and by the route role of tick_kernel (tick.hip.h).
-template <int kThreads, int kEnt = kLzEntriesMax>
+// kChk: built with the exact treeify check (step 0; it runs when prm.bin16 is set).  A template parameter because the check's
+// loads live across the ordering step: in the 512-entry class (80 registers at six workgroups per CU) they would spill, and any
+// scratch use costs every dispatch of the stream — that class is built without it, and a checked Route takes the 1024-entry class.
+template <int kThreads, int kEnt = kLzEntriesMax, bool kChk = true>
 __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned char* smem, const int64_t q_first, const int64_t q_stride, const int block_id) {
     int4* probe_in = prm.probe_g;          // not __restrict__: a handed-over query's lists are written here and read back
     int32_t* nprobe_in = prm.nprobe_g;
@@ -105,6 +108,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     constexpr int kLzHtSize = lz_ht_size(kEnt), kLzEntries = kEnt, kLzSortMax = lz_sort_max(kEnt);
     constexpr int kLzStageU = lz_stage_u(kEnt), kLzKeep = lz_keep(kEnt);
     static_assert(kEnt == 512 || kEnt == 1024 || kEnt == 2048, "size classes");
+    static_assert(!(kChk && kEnt == 512), "the 512-entry class has no registers for the check");
     size_t o = 0;
     uint64_t* ht = reinterpret_cast<uint64_t*>(smem + o);        o += static_cast<size_t>(kLzHtSize) * 8;
     int4* plist = reinterpret_cast<int4*>(smem + o);             o += static_cast<size_t>(TP) * 16;
@@ -120,20 +124,23 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     uint16_t* rk = reinterpret_cast<uint16_t*>(smem + o);        o += static_cast<size_t>(kEnt) * 2;   // entries per (score, bucket) rank: > 1 = collision
     uint16_t* lrank = reinterpret_cast<uint16_t*>(smem + o);     o += static_cast<size_t>(kEnt) * 2;   // (score, bucket) rank of each entry
     uint32_t* gk = reinterpret_cast<uint32_t*>(smem + o);        o += static_cast<size_t>(kEnt) * 4;   // the keys grouped by their top bits (rank pass)
-    int32_t* nprobe_l = reinterpret_cast<int32_t*>(smem + o);    // [TD] fused probe: partitions probed per table
+    int32_t* nprobe_l = reinterpret_cast<int32_t*>(smem + o);    o += static_cast<size_t>(TD) * 4;   // [TD] fused probe: partitions probed per table
+    int32_t* part0 = reinterpret_cast<int32_t*>(smem + o);       o += static_cast<size_t>(TD) * 4;   // first partition of each table (global numbering)
+    int32_t* pglob = reinterpret_cast<int32_t*>(smem + o);       // [TP] global number of each probed partition: its row of bin16
     // collision records alias the histogram (free once the levels are in): element, prefix rank, id, sequence
     int32_t* c_elem = bins;
     int32_t* c_lt = bins + kLzCollMax;
     int32_t* c_id = bins + 2 * kLzCollMax;
     int32_t* c_seq = bins + 3 * kLzCollMax;
 
-    __shared__ int s_u, s_R, s_ncoll, s_bad, s_b, s_cnt, s_short;
+    __shared__ int s_u, s_R, s_ncoll, s_bad, s_b, s_cnt, s_short, s_susp;
     constexpr uint32_t ht_mask = kLzHtSize - 1;
     constexpr int ht_shift = (kEnt == 2048) ? 32 - 12 : (kEnt == 1024) ? 32 - 11 : 32 - 10;   // 32 - log2(hash slots)
     unsigned long long lt_mask = 0;
 
-    for (int i = tid; i < TD; i += nthreads) ids_base[i] = prm.tables[i].ids_base;
+    for (int i = tid; i < TD; i += nthreads) { ids_base[i] = prm.tables[i].ids_base; part0[i] = static_cast<int32_t>(prm.tables[i].part_base); }
     for (int i = tid; i < kLzHtSize; i += nthreads) ht[i] = kLzEmpty;
+    if (kChk && prm.bin16) for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;   // the check's counters (step 0) start clear
     if (block_id == 0 && tid == 0) *prm.ovf_next = 0;   // the other counter, for the next call (stream-ordered after this one)
     __syncthreads();                                    // ids_base is read when the first query's probe list is completed
 
@@ -251,6 +258,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
                 if (step < nprobe_l[td]) e = plist[i];
                 plist[i] = e;
                 pbase[i] = ids_base[td] + e.z;      // (a division by P per tuple trip otherwise: the table of a probe is i / P)
+                pglob[i] = part0[td] + e.x;
                 pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
             }
         } else {
@@ -260,10 +268,11 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
                 if (step < nprobe_in[qi * TD + td]) e = probe_in[qi * TP + i];
                 plist[i] = e;
                 pbase[i] = ids_base[td] + e.z;
+                pglob[i] = part0[td] + e.x;
                 pkv[i] = make_uint2((static_cast<uint32_t>(e.y) << 16) | static_cast<uint32_t>(i), static_cast<uint32_t>(e.w));
             }
         }
-        if (tid == 0) { s_u = 0; s_R = TP; s_ncoll = 0; s_bad = 0; s_short = 0; pkv[TP] = make_uint2(0xFFFFFFFFu, 0u); }
+        if (tid == 0) { s_u = 0; s_R = TP; s_ncoll = 0; s_bad = 0; s_short = 0; s_susp = 0; pkv[TP] = make_uint2(0xFFFFFFFFu, 0u); }
         __syncthreads();
         LZ_STAMP(1);
         LZ_STOP(1)
@@ -274,6 +283,52 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         asm volatile("" : "+v"(tid));
         lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         lt_mask = (1ull << lane) - 1ull;
+        // ---- 0. exact treeify check, first half (prm.bin16 != null: opaque ids, or asked for) ----------------------------
+        // bestScore treeifies a bin when NINE distinct live ids of the probed partitions share it (HashMap.putVal at cap0, no
+        // resize in reach: PIS:619) — including ids of partitions the walk below never loads.  The bins of ALL ids of the probed
+        // partitions are read here (bin16: one 128-byte row per 64-id partition, requested before the ordering below and counted
+        // after it) into 4-bit counters over the bins folded to 13 bits (the histogram's 4 KB, clear at this point): an id is
+        // counted once per table holding it and several bins share a counter, so a counter below nine PROVES its bins stay
+        // chains.  A counter that reaches nine is looked at exactly (second half, behind the barrier): rare.
+        constexpr int kChkU = 5;
+        uint2 chk_v[kChkU];
+        int chk_n[kChkU];
+        const int chk_cps = prm.bin16_shift - 2;                       // 8-byte chunks (four bins) per partition row, log2
+        const int chk_items = (kChk && prm.bin16) ? (TP << chk_cps) : 0;
+        const bool chk_once = chk_items <= nthreads * kChkU;           // everything in one round of loads (BASELINE shapes)
+        auto chk_load = [&](const int it0) {
+#pragma unroll
+            for (int v = 0; v < kChkU; v++) {
+                const int it = it0 + v * nthreads;
+                chk_v[v] = make_uint2(0u, 0u); chk_n[v] = 0;
+                if (it < chk_items) {
+                    const int pi = it >> chk_cps, ch = it & ((1 << chk_cps) - 1);
+                    const int4 pr = plist[pi];
+                    const int rem = pr.w - ch * 4;
+                    if (pr.x >= 0 && rem > 0) {
+                        chk_v[v] = *reinterpret_cast<const uint2*>(prm.bin16 + (static_cast<int64_t>(pglob[pi]) << prm.bin16_shift) + ch * 4);
+                        chk_n[v] = min(rem, 4);
+                    }
+                }
+            }
+        };
+        auto chk_count = [&]() {
+            bool sus = false;
+#pragma unroll
+            for (int v = 0; v < kChkU; v++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < chk_n[v]) {
+                        const uint32_t b16 = ((k < 2 ? chk_v[v].x : chk_v[v].y) >> ((k & 1) * 16)) & 0xFFFFu;
+                        const uint32_t sh = (b16 & 7u) * 4u;
+                        const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(bins) + ((b16 & 8191u) >> 3), 1u << sh);
+                        sus = sus || (((old >> sh) & 15u) >= 8u);    // this id is the ninth (or later) of its counter
+                    }
+                }
+            }
+            if (sus) s_susp = 1;
+        };
+        if (chk_items > 0 && chk_once) chk_load(tid);
         // ---- 1. order the probed partitions by (distance, Java order); prefix sums of their sizes ----------------
         for (int i = tid; i < TP; i += nthreads) {
             const uint2 me = pkv[i];
@@ -292,17 +347,90 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
             if ((mk >> 16) == 0x7FFFu) atomicMin(&s_R, rank);   // unused steps sort last: the first of them ends the list
             if (rank == TP - 1) pcs[TP] = cum + static_cast<int>(me.y);
         }
+        if (chk_items > 0) {
+            if (chk_once) chk_count();
+            else for (int it0 = tid; it0 < chk_items; it0 += nthreads * kChkU) { chk_load(it0); chk_count(); }   // (block-uniform trips)
+        }
         __syncthreads();
         LZ_STAMP(2);
         LZ_STOP(2)
         const int R = s_R;                           // valid probes occupy sorted positions [0, R)
         bool overflow = false;
+        if (chk_items > 0 && s_susp) {
+            // ---- 0. second half (rare): the ids behind the counters that reached nine, looked at exactly ----------------
+            // Sweep A counts again into the cleared table and marks every counter whose increment is the ninth or later in a
+            // bitmap (a counter passes nine before it can wrap, and a wrap only carries into its neighbour: more marks, never
+            // fewer); sweep B collects every live entry of a marked counter as (true bin, id); then first occurrences of an id
+            // (it comes once per table holding it) and, per TRUE bin, the distinct ids: nine or more = the JVM treeifies.
+            uint32_t* mark = reinterpret_cast<uint32_t*>(ht);                  // 8192 bits = 128 slots (ht is all-empty here: restored below)
+            uint64_t* cl = ht + 128;                                           // up to kChkList collected (bin << 32 | id)
+            uint64_t* cf = cl + 256;                                           // first occurrences
+            constexpr int kChkList = 256;
+            static_assert(128 + 2 * 256 <= lz_ht_size(512), "the check's scratch fits the smallest hash table");
+            for (int i = tid; i < 256; i += nthreads) mark[i] = 0u;
+            for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;
+            __syncthreads();
+            for (int it = tid; it < chk_items; it += nthreads) {
+                const int pi = it >> chk_cps, ch = it & ((1 << chk_cps) - 1);
+                const int4 pr = plist[pi];
+                const int rem = pr.w - ch * 4;
+                if (pr.x < 0 || rem <= 0) continue;
+                const uint2 vv = *reinterpret_cast<const uint2*>(prm.bin16 + (static_cast<int64_t>(pglob[pi]) << prm.bin16_shift) + ch * 4);
+                for (int k = 0; k < min(rem, 4); k++) {
+                    const uint32_t b16 = ((k < 2 ? vv.x : vv.y) >> ((k & 1) * 16)) & 0xFFFFu, f = b16 & 8191u;
+                    const uint32_t sh = (f & 7u) * 4u;
+                    const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(bins) + (f >> 3), 1u << sh);
+                    if (((old >> sh) & 15u) >= 8u) atomicOr(&mark[f >> 5], 1u << (f & 31u));
+                }
+            }
+            __syncthreads();
+            for (int it = tid; it < chk_items; it += nthreads) {
+                const int pi = it >> chk_cps, ch = it & ((1 << chk_cps) - 1);
+                const int4 pr = plist[pi];
+                const int rem = pr.w - ch * 4;
+                if (pr.x < 0 || rem <= 0) continue;
+                const uint2 vv = *reinterpret_cast<const uint2*>(prm.bin16 + (static_cast<int64_t>(pglob[pi]) << prm.bin16_shift) + ch * 4);
+                for (int k = 0; k < min(rem, 4); k++) {
+                    const uint32_t b16 = ((k < 2 ? vv.x : vv.y) >> ((k & 1) * 16)) & 0xFFFFu, f = b16 & 8191u;
+                    if (!((mark[f >> 5] >> (f & 31u)) & 1u)) continue;
+                    const int32_t id = prm.ids[pbase[pi] + ch * 4 + k];      // bin16 rows are in the id list's order
+                    if (prm.deleted_bits && ((prm.deleted_bits[id >> 5] >> (id & 31)) & 1u)) continue;                 // PIS:739: never put
+                    const int c = atomicAdd(&s_ncoll, 1);
+                    if (c < kChkList) cl[c] = (static_cast<uint64_t>(b16) << 32) | static_cast<uint32_t>(id);
+                }
+            }
+            __syncthreads();
+            const int ncl = s_ncoll;
+            if (ncl > kChkList) {
+                overflow = true;                      // too many suspects to settle here: the full select checks exactly
+            } else {
+                for (int i = tid; i < ncl; i += nthreads) {
+                    const uint64_t me = cl[i];
+                    bool first = true;
+                    for (int j = 0; j < i; j++) first = first && (cl[j] != me);      // the same id (hence the same bin) from another table
+                    cf[i] = first ? me : ~0ull;
+                }
+                __syncthreads();
+                for (int i = tid; i < ncl; i += nthreads) {
+                    const uint64_t me = cf[i];
+                    if (me == ~0ull) continue;
+                    int same = 0;
+                    for (int j = 0; j < ncl; j++) same += (cf[j] != ~0ull) && ((cf[j] >> 32) == (me >> 32));
+                    if (same >= 9) s_bad = 1;         // nine distinct live ids in one bin: the JVM treeifies it
+                }
+            }
+            __syncthreads();
+            if (s_bad) overflow = true;
+            for (int i = tid; i < 128 + 2 * kChkList; i += nthreads) ht[i] = kLzEmpty;
+            if (tid == 0) s_ncoll = 0;
+            __syncthreads();
+        }
         int r0 = 0, u = 0;
         int dbg_outer = 0, dbg_inner = 0, dbg_reload = 0, dbg_nitb = 0;
         (void)dbg_outer; (void)dbg_inner; (void)dbg_reload; (void)dbg_nitb;   // read only in FSPANN_DEBUG_STAMPS builds
         bool force_full = false;
         // ---- 2. walk the distance levels ---------------------------------------------------------------------------
-        while (r0 < R && u < prm.limit) {
+        while (r0 < R && u < prm.limit && !overflow) {
             const int need = prm.limit - u;
             // r_fit = last level boundary whose cumulated tuples stay <= need; r_nofit = the boundary after it (the end of
             // the level that can cross `limit`).  Every wave computes the same values: the loop is wave-uniform.
@@ -621,6 +749,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         // ---- clear exactly the slots this query used ---------------------------------------------------------------
         const int used = min(s_u, kLzEntries);
         for (int i = tid; i < used; i += nthreads) ht[ulist[i]] = kLzEmpty;
+        if (kChk && prm.bin16) for (int i = tid; i < 1024; i += nthreads) bins[i] = 0;   // step 0 of the next query counts into it
         __syncthreads();
         LZ_STAMP(7);
     }
@@ -630,10 +759,10 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 #undef LZ_INSERT
 }
 
-template <int kThreads, int kEnt>
+template <int kThreads, int kEnt, bool kChk>
 __global__ __launch_bounds__(kThreads, (kEnt <= 512 ? 6 : (kEnt <= 1024 ? 4 : 2))) void route_select_lazy_kernel(RouteParams prm) {
     extern __shared__ __align__(16) unsigned char smem[];
-    route_lazy_run<kThreads, kEnt>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
+    route_lazy_run<kThreads, kEnt, kChk>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
 }
 
 }  // namespace fspann

@@ -281,6 +281,31 @@ class FspannContext:
                 self.L.fspann_dev_free(self._h, p)
         return count < 0
 
+    def route_flags_bounded(self, codes, limit, probe_override=-1):
+        """Diagnostics: which queries end FLAGGED (count = -1) when fspann_route_dev runs the way stage A.5 calls it — first
+        `limit` entries, no counters, so the bounded select runs where it is legal and hands over what it cannot hold or what
+        its exact treeify check catches; the full select then flags a treeified bestScore map.  Nothing is resolved."""
+        codes = _c(codes, np.uint64).reshape(-1, self.TD, self.W)
+        nq = codes.shape[0]
+        bufs = []
+
+        def dev(nbytes):
+            p = C.c_void_p()
+            N.check(self.L.fspann_dev_alloc(self._h, nbytes, C.byref(p)))
+            bufs.append(p)
+            return p
+        try:
+            d_codes, d_ids, d_cnt = dev(codes.nbytes), dev(nq * limit * 4), dev(nq * 4)
+            N.check(self.L.fspann_h2d(self._h, d_codes, _p(codes), codes.nbytes))
+            N.check(self.L.fspann_route_dev(self._h, nq, d_codes, probe_override, limit, limit, d_ids, None, d_cnt, None, None))
+            count = np.zeros(nq, np.int32)
+            N.check(self.L.fspann_d2h(self._h, _p(count), d_cnt, nq * 4))
+            self.unmodelled_queries(reset=True)
+        finally:
+            for p in bufs:
+                self.L.fspann_dev_free(self._h, p)
+        return count < 0
+
     # -- Refine ----------------------------------------------------------------------
     def refine(self, q, cand, cand_ids, cand_count, k):
         cand = np.ascontiguousarray(cand)

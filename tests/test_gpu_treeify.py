@@ -175,9 +175,12 @@ def test_bounded_select_hand_over_ends_in_the_host_model(pkg, oracle):
         assert np.array_equal(lazy["ids"][i, :lazy["count"][i]], ids[i, :lazy["count"][i]]), i
 
 
-def test_search_call_is_completed_for_flagged_queries(pkg, oracle):
+@pytest.mark.parametrize("mode", [0, 2, 1])
+def test_search_call_is_completed_for_flagged_queries(pkg, oracle, mode):
     """fspann_search_store_dev leaves a flagged query empty (count -1, nothing scored); fspann_search_store_finish_dev finishes its
-    Route on the host and scores the batch again: every query then equals oracle.search."""
+    Route on the host and scores the batch again: every query then equals oracle.search.  In auto mode (0) and with the bounded
+    select forced (2) the flag comes from the bounded select's own exact check over bin16 (opaque ids) -> hand-over -> full
+    select; mode 1 is the full select alone."""
     import torch
     n, d, B, K = 8000, 16, 64, 5
     sc = make_scene(oracle, n=n, d=d, T=4, D=1, m=10, lam=2, B=B, seed=77)
@@ -198,7 +201,7 @@ def test_search_call_is_completed_for_flagged_queries(pkg, oracle):
     with _ctx(pkg, sc, jh) as ctx:
         _import(ctx, o)
         ctx.store_set(sc["X"])
-        ctx.set_route_mode(1)                                # the full select: exact detection
+        ctx.set_route_mode(mode)
         qd = torch.from_numpy(Q).to(dev)
         oi = torch.zeros((8, K), dtype=torch.int32, device=dev)
         od = torch.zeros((8, K), dtype=torch.float64, device=dev)
@@ -219,6 +222,99 @@ def test_search_call_is_completed_for_flagged_queries(pkg, oracle):
         assert np.array_equal(np.where(np.arange(B)[None] < ref["sel_count"][:, None], sel.cpu().numpy(), -1), ref["sel"][:, :B])
         assert np.array_equal(oi.cpu().numpy(), ref["ids"]) and np.array_equal(od.cpu().numpy(), ref["dist"])
         assert np.array_equal(oc.cpu().numpy(), ref["count"])
+
+
+def _crowd(oracle, o, sc, codes, q, k, rng, positions=None):
+    """hashCodes = decimal ones, except k of query q's candidates — spread over its WHOLE list, every score level, far beyond the
+    first B — which get k different hashCodes falling into ONE bin of the 32768-table.  Returns (jh, the crowded ids)."""
+    n = sc["params"]["n"]
+    ids, _, count, _ = o.route(codes)
+    pos = np.unique(np.linspace(0, count[q] - 1, k).astype(int)) if positions is None else np.asarray(positions)
+    crowd = ids[q, pos]
+    jh = oracle.decimal_hashes(n).copy()
+    h = jh.view(np.uint32)
+    free = np.setdiff1d(np.arange(32768), (h ^ (h >> 16)) & 32767)       # a bin no decimal hashCode of this id space falls into
+    b = int(free[rng.integers(0, len(free))])
+    jh[crowd] = _spread_inv(b + 32768 * (1 + rng.permutation(len(crowd)).astype(np.int64)))
+    return jh, crowd
+
+
+def _max_bin_load(jh, lists, counts):
+    """Per query: the largest number of (distinct, live — the lists hold nothing else) ids sharing one bin of the 32768-table."""
+    h = jh.view(np.uint32)
+    sp = (h ^ (h >> 16)) & 32767
+    return np.array([np.unique(sp[l[:c]], return_counts=True)[1].max() for l, c in zip(lists, counts)])
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_bounded_select_sees_a_bin_filled_by_ids_it_never_loads(pkg, oracle, mode):
+    """The hole VERDICT r03 named: opaque ids (caller-supplied String.hashCode) whose codes crowd ONE bin across DIFFERENT scores
+    and partitions the bounded select never loads.  The JVM treeifies that bin and reorders it; the bounded select's exact check
+    (bin16: the bins of ALL ids of the probed partitions) must flag exactly those queries in auto mode and in mode 2 — and
+    fspann_route's answer (full select -> host model for them) is the oracle's list for EVERY query.  Eight in a bin is a chain
+    (not flagged), nine a tree; a deleted id is never put (PIS:739) and does not count."""
+    B = 64
+    total_flagged = total_clean = 0
+    for seed, k, ndel in ((0, 12, 0), (1, 10, 0), (2, 8, 0), (3, 10, 2), (4, 16, 0), (5, 40, 0)):
+        rng = np.random.default_rng(4100 + seed)
+        n = 20000
+        sc = make_scene(oracle, n=n, d=16, T=8, D=1, m=12, lam=2, B=B, seed=300 + seed)
+        o = sc["oracle"]
+        Q = rng.standard_normal((12, 16))
+        codes = o.encode(Q)
+        jh, crowd = _crowd(oracle, o, sc, codes, 3, k, rng)
+        deleted = None
+        if ndel:
+            deleted = np.zeros(n, np.uint8)
+            deleted[crowd[[1, len(crowd) // 2]]] = 1         # two of the ten are deleted: eight puts, no tree
+        o.set_id_meta(n, jh, deleted)
+        o.build_index(sc["X64"])                             # (the staging map's order depends on the hashCodes)
+        ids, score, count, _ = o.route(codes)
+        want = o.route_treeified(codes)
+        assert not o.unmodelled
+        # what this scene is for: the crowded ids of query 3 sit on several score levels, most of them behind the first B entries
+        # (re-cutting the partitions with the new hashCodes can move a crowded id out of reach: what counts is what is in the list)
+        where = np.flatnonzero(np.isin(ids[3, :count[3]], crowd))
+        load = _max_bin_load(jh, ids, count)
+        assert np.array_equal(want, load >= 9), (seed, load)            # the oracle's own flag, re-derived from first principles
+        assert load[3] == len(where) and len(np.unique(score[3, where])) >= 3 and (where < B).sum() < 9, (seed, where)
+        with _ctx(pkg, sc, jh, B=B) as ctx:
+            if deleted is not None:
+                ctx.set_id_meta(n, jh, deleted)
+            _import(ctx, o)
+            ctx.set_route_mode(mode)
+            res = ctx.route(codes, limit=B, counters=False)
+            info = ctx.last_route_info()
+            assert info["lazy"], "the bounded select must be the one that ran"
+            assert info["overflowed"] >= int(want.sum())     # every query the JVM would treeify was handed over
+            assert ctx.unmodelled_queries() == 0             # ... and finished by the host model inside fspann_route
+            # the bounded select alone (device entry point, nothing resolved): flagged queries == the oracle's
+            flags = ctx.route_flags_bounded(codes, limit=B)
+        assert np.array_equal(flags, want), (seed, np.flatnonzero(flags != want))
+        for i in range(len(Q)):
+            c = min(count[i], B)
+            assert res["count"][i] == c, (seed, i)
+            assert np.array_equal(res["ids"][i, :c], ids[i, :c]), (seed, i, bool(want[i]))
+            assert np.array_equal(res["score"][i, :c], score[i, :c]), (seed, i)
+        total_flagged += int(want.sum())
+        total_clean += int((~want).sum())
+    assert total_flagged >= 3 and total_clean > 0
+
+
+def test_decimal_ids_can_ask_for_the_exact_check(pkg, oracle, monkeypatch):
+    """FSPANN_ROUTE_BINCHECK=1: decimal ordinals run the same exact check (bin16 is built for them too); lists unchanged."""
+    monkeypatch.setenv("FSPANN_ROUTE_BINCHECK", "1")
+    sc = make_scene(oracle, n=30000, d=16, T=8, D=2, m=12, lam=2, B=256, seed=5)
+    o = sc["oracle"]
+    codes = o.encode(sc["rng"].standard_normal((40, 16)))
+    ids, score, count, _ = o.route(codes)
+    with _ctx(pkg, sc, None, B=256) as ctx:
+        _import(ctx, o)
+        res = ctx.route(codes, limit=256, counters=False)
+        assert ctx.last_route_info()["lazy"]
+    for i in range(40):
+        c = min(count[i], 256)
+        assert res["count"][i] == c and np.array_equal(res["ids"][i, :c], ids[i, :c]) and np.array_equal(res["score"][i, :c], score[i, :c])
 
 
 def test_host_pipeline_answers_flagged_queries(pkg, oracle):
