@@ -703,8 +703,36 @@ def main():
         same_codes = bool(torch.equal(codes_m, codes_e))
         if not same_codes:
             raise SystemExit("bench: the MFMA coding path and the exact fp64 kernel disagree on the base rows")
+        # north_star's formulation at the QUERY side: the same MFMA pre-filter + exact re-check for one batch of Q queries, stand-alone
+        # (fspann_set_encode_mode(2)), next to the exact fp64 kernel (mode 1) — solo launches, events around 50 calls each
+        q_enc = {}
+        codes_q = torch.zeros((Q, TD, W), dtype=torch.int64, device=dev)
+        for mode_e, name_e in ((1, "exact"), (2, "mfma")):
+            ctx.set_encode_mode(mode_e)
+            for _ in range(5):
+                ctx.encode_dev(Q, q_all[0].data_ptr(), F32, codes_q.data_ptr(), 0, bad_e.data_ptr())
+            ctx.sync()
+            e0.record(streams[0])
+            for i in range(50):
+                ctx.encode_dev(Q, q_all[i % NB].data_ptr(), F32, codes_q.data_ptr(), 0, bad_e.data_ptr())
+            e1.record(streams[0])
+            ctx.sync()
+            q_enc[name_e] = dict(us_per_call=round(e0.elapsed_time(e1) * 1e3 / 50, 2), rechecked_pairs=int(ctx.last_encode_rechecked()) if mode_e == 2 else None,
+                                 codes=codes_q.clone())
+        ctx.set_encode_mode(0)
+        if not torch.equal(q_enc["exact"]["codes"], q_enc["mfma"]["codes"]):
+            raise SystemExit("bench: MFMA and exact coding disagree on a query batch")
+        for v_ in q_enc.values():
+            del v_["codes"]
         fl_i = 2.0 * nq_e * d * TD * m
         encode_stage = dict(
+            query_side_mfma_vs_exact=dict(
+                rows=Q, exact_fp64_valu=q_enc["exact"], mfma_prefilter_plus_recheck=q_enc["mfma"], pairs=Q * TD * m, codes_equal=True,
+                shipped="exact" if q_enc["exact"]["us_per_call"] <= q_enc["mfma"]["us_per_call"] else "exact (inside front_kernel)",
+                note="whole fspann_encode_dev calls back to back on one stream (mode 2 = clear of the code words + encode_mfma_kernel + "
+                     "encode_fix_kernel: three dependent launches); at Q rows the 64 x 256 MFMA tile yields Q/64 workgroups for 256 CUs, "
+                     "and in the default pipeline the exact kernel's workgroups ride inside front_kernel beside Route's, where they are off "
+                     "the critical path (DESIGN.md §3.1)"),
             query_side=dict(kernel="encode_exact_kernel<float,4> (its workgroups ride inside front_kernel in the default pipeline)", rows=Q,
                             flops_per_launch=fl_q, ms=round(enc_ms, 5), tflops=round(fl_q / (enc_ms * 1e-3) / 1e12, 3), peak=FP64_VALU_PEAK,
                             frac=round(fl_q / (enc_ms * 1e-3) / 1e12 / FP64_VALU_PEAK, 5),
@@ -750,6 +778,69 @@ def main():
                 continue
             el_v, _, _ = timed(vm, args.steps, max(2, args.warmup), nact=nctx)
             variants[vm] = dict(value=round(Q * args.steps / el_v, 1), unit="queries/s", ms_per_step=round(el_v * 1000.0 / args.steps, 4), note=note)
+
+    # ---------------- the operator surface's OWN call pattern (N = 1) ------------------------------------------------------------
+    # QueryService.search(QueryToken) is called once per query by the reference's loop (ForwardSecureANNSystem.java:636-748), so the
+    # Java adapter (GpuQueryServiceImpl.search) issues, per query and through HOST pointers: fspann_route(nq = 1, limit = B) ->
+    # the host's load + decrypt loop -> fspann_refine(nq = 1, fp64 rows) — the token's codes come from fspann_encode(nq = 1) at
+    # token creation.  Timed here exactly like that through the same C entry points (ctypes instead of JNI; the plaintext rows are
+    # copied out of the base array where the JVM would decrypt: that copy is reported, not counted), next to the batched mirror
+    # searchBatch (one fspann_route + one fspann_refine for all queries of a batch).
+    operator_surface = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        nsamp = 256 if B <= 1024 else 64
+        qs_ = Qall[0][:nsamp].astype(np.float64)
+        lat = {k_: [] for k_ in ("encode", "route", "host_rows", "refine")}
+        for i in range(8 + nsamp):
+            q1 = qs_[i % nsamp][None]
+            t0_ = time.perf_counter()
+            c1 = ctx.encode(q1)
+            t1_ = time.perf_counter()
+            r1 = ctx.route(c1, probe_override=probe_passes[-1], limit=B, counters=False)
+            t2_ = time.perf_counter()
+            cN = int(r1["count"][0])
+            rows = X[r1["ids"][0, :cN]].astype(np.float64)[None]
+            t3_ = time.perf_counter()
+            if cN > 0:
+                ctx.refine(q1, rows, np.arange(cN, dtype=np.int32)[None], np.array([cN], np.int32), k)
+            t4_ = time.perf_counter()
+            if i >= 8:
+                for k_, v_ in (("encode", t1_ - t0_), ("route", t2_ - t1_), ("host_rows", t3_ - t2_), ("refine", t4_ - t3_)):
+                    lat[k_].append(v_ * 1e6)
+        gpu_calls = np.array(lat["route"]) + np.array(lat["refine"])
+        # the batched mirror: the same three calls for all nsamp queries at once
+        tb0 = time.perf_counter()
+        cB = ctx.encode(qs_)
+        tb1 = time.perf_counter()
+        rB = ctx.route(cB, probe_override=probe_passes[-1], limit=B, counters=False)
+        tb2 = time.perf_counter()
+        cntB = rB["count"].astype(np.int32)
+        rowsB = np.zeros((nsamp, B, d), np.float64)
+        for i in range(nsamp):
+            rowsB[i, :cntB[i]] = X[rB["ids"][i, :cntB[i]]]
+        tb3 = time.perf_counter()
+        ctx.refine(qs_, rowsB, np.tile(np.arange(B, dtype=np.int32), (nsamp, 1)), cntB, k)
+        tb4 = time.perf_counter()
+        del rowsB
+
+        def pct(a, p_):
+            return round(float(np.percentile(np.asarray(a), p_)), 1)
+        operator_surface = dict(
+            per_query=dict(queries=nsamp, unit="us per query",
+                           route_plus_refine=dict(p50=pct(gpu_calls, 50), p99=pct(gpu_calls, 99), mean=round(float(gpu_calls.mean()), 1)),
+                           encode=dict(p50=pct(lat["encode"], 50), p99=pct(lat["encode"], 99)),
+                           route=dict(p50=pct(lat["route"], 50), p99=pct(lat["route"], 99)),
+                           refine_f64_rows=dict(p50=pct(lat["refine"], 50), p99=pct(lat["refine"], 99)),
+                           host_rows_copy_not_counted=dict(p50=pct(lat["host_rows"], 50)),
+                           queries_per_s=round(1e6 / float(gpu_calls.mean()), 1),
+                           note="GpuQueryServiceImpl.search's pattern: fspann_route(nq = 1, limit = B, host pointers: H2D of the codes, kernels, "
+                                "D2H of F_q) then fspann_refine(nq = 1, fp64 rows, host pointers: H2D of B x d x 8 bytes, scan, D2H); synchronous, "
+                                "one query in flight, Python ctypes call overhead included"),
+            batched=dict(queries=nsamp, unit="us per query", encode=round((tb1 - tb0) * 1e6 / nsamp, 2), route=round((tb2 - tb1) * 1e6 / nsamp, 2),
+                         refine_f64_rows=round((tb4 - tb3) * 1e6 / nsamp, 2), host_rows_copy_not_counted=round((tb3 - tb2) * 1e6 / nsamp, 2),
+                         queries_per_s=round(nsamp / ((tb2 - tb1) + (tb4 - tb3)), 1),
+                         note="searchBatch (GpuQueryServiceImpl.searchBatch / operators.QueryServiceImpl.search_batch): ONE fspann_route and ONE "
+                              "fspann_refine(fp64 rows) for the whole batch through the same host-pointer entry points (PCIe-inclusive)"))
 
     # ---------------- end to end (N = 1): the native host candidate pipeline — Route on the GPU, AES-256-GCM open of F_q's records
     # on the host cores into pinned staging, H2D, Refine — three batches in flight (fspann_pipeline_*) ------------
@@ -909,6 +1000,37 @@ def main():
                               achieved=round(bytes4 / (scan_ms * 1e-3) / 1e9, 1), frac=round(bytes4 / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               note="two 3.2 GB blocks alternate; events attached to the scan kernel; scan_plus_merge_ms = whole fspann_refine_dev call")
             del cand4
+        # (c) fp64 rows, fp64 query — what the JVM hands over (double[] from decryptFromPoint): refine_stream_kernel<double,double,16,false>,
+        # algorithmic bytes = Q * (B*d*8 + d*8 + k*8); 8 distinct blocks are cycled (2.1 GB at config #2)
+        NB64 = 8
+        cand64 = torch.randn((NB64, Q, B, d), dtype=torch.float64, device=dev)
+        q64 = q_all[0].double()
+        ids64 = torch.arange(Q * B, dtype=torch.int32, device=dev).view(Q, B)
+        cnt64 = torch.full((Q,), B, dtype=torch.int32, device=dev)
+        b0 = bufs[0]
+        torch.cuda.synchronize()
+
+        def r64(i):
+            ctx.refine_dev(Q, q64.data_ptr(), pkg._native.F64, cand64[i % NB64].data_ptr(), pkg._native.F64, B, ids64.data_ptr(), cnt64.data_ptr(), k,
+                           b0["topk"][1].ids.data_ptr(), b0["topk"][1].dist.data_ptr(), b0["out_cnt"].data_ptr(), b0["scored"].data_ptr())
+        for i in range(4):
+            r64(i)
+        ctx.sync()
+        ctx.refine_timing_begin(32, 1)
+        for i in range(32):
+            r64(i)
+            ctx.sync()                        # solo dispatches
+        nl64, tms64 = ctx.refine_timing_end()
+        bytes64 = Q * (B * d * 8 + d * 8 + k * 8)
+        ms64 = tms64 / max(1, nl64)
+        f64_rows = dict(kernel="refine_stream_kernel<double,double,16,false>", algorithmic_bytes_per_launch=bytes64, launches=nl64,
+                        avg_launch_ms=round(ms64, 5), achieved=round(bytes64 / (ms64 * 1e-3) / 1e9, 1),
+                        frac=round(bytes64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        note="the scan over fp64 candidate rows and an fp64 query (the dtype GpuQueryServiceImpl hands over), device-resident "
+                             "blocks, solo dispatches with kernel-attached events")
+        del cand64, q64
+    else:
+        f64_rows = None
     kname = "refine_stream_kernel<float,float,32,%s>" % ("true" if mode == "store" else "false")
     if args.pipeline == "front" and not use_tick and mode == "dense" and B <= 256:
         kname = "refine_stream_fix_kernel<false> (the streaming scan whose workgroups first finish queries the bounded select handed over)"
@@ -933,7 +1055,7 @@ def main():
                                      note="the same kernel's sampled dispatches while kernels of the other contexts run beside it (what a kernel "
                                           "trace of this command averages over): it shares HBM then, so this is not a roofline of the kernel")
                                 if overlapped_main else None),
-                    hbm_proof=hbm_proof, cfg4_shape=cfg4_shape)
+                    hbm_proof=hbm_proof, cfg4_shape=cfg4_shape, f64_rows=f64_rows)
 
     # Route (probe + select) is bound by dependent L2 rounds and LDS atomics, not by HBM or MFMA; its algorithmic bytes
     # (per (t,d) search + rep/id-range fetch + P*S ids) are reported for scale.
@@ -1085,8 +1207,11 @@ def main():
                 done2 += len(qall64)
                 if time.perf_counter() - t2 > 5.0 or reps2 >= 200:
                     break
-            cpu["all_cores"] = dict(value=round(done2 / (time.perf_counter() - t2), 1), unit="queries/s", cores=nthr,
-                                    note="the same port, OpenMP over queries on every core this process may use")
+            v_all = done2 / (time.perf_counter() - t2)
+            cpu["all_cores"] = dict(value=round(v_all, 1), unit="queries/s", threads=nthr,
+                                    cores_worth=round(v_all / max(cpu["value"], 1e-9), 2),
+                                    note="the same port with one thread per logical CPU the process may be scheduled on; the box gives this process only "
+                                         "a share of them: `cores_worth` = this rate / the single-thread rate = how many cores' worth of work it actually got")
 
     if use_dist and comms is not None:
         # merged result = every rank's top-k in rank order.  EVERY rank checks EVERY slice: the buffer the path's own collective
@@ -1105,6 +1230,48 @@ def main():
         ranks_verified = True
     else:
         ranks_verified = None
+    # ---------------- the reference's SHIPPED profiles, as children of the default command (rank 0, N = 1) -------------------------
+    # config_sift1m.json:44-56,116-128 (SIFT_P4_FAST, SIFT_P10_HIGH; k = 100): the only configurations BASELINE.md holds reference
+    # numbers for.  Each runs as its own `bench.py --workload ...` process AFTER everything above (this process is idle meanwhile and
+    # keeps only its buffers), on the clustered stand-in for SIFT; its line is summarised under `extra.shipped_profiles`.
+    extra = None
+    if rank == 0 and world == 1 and extras and not args.no_shipped:
+        import subprocess
+        torch.cuda.synchronize()
+        shipped_out = {}
+        for wname in ("sift1m_P4_FAST", "sift1m_P10_HIGH"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", wname, "--k", "100", "--data", "clustered", "--steps", str(args.shipped_steps),
+                   "--warmup", "3", "--prewarm", "10", "--cpu-sample", "64", "--no-shipped", "--solo-tail", "0"]
+            t_c = time.perf_counter()
+            try:
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+                line = [x for x in pr.stdout.splitlines() if x.startswith("{")]
+                if pr.returncode != 0 or not line:
+                    shipped_out[wname] = dict(error=("rc %d: " % pr.returncode) + pr.stderr[-400:])
+                    continue
+                cj = json.loads(line[-1])
+                st_ = cj.get("stages_ms") or {}
+                tot_ = sum(v for v in st_.values() if v) or 1.0
+                rf_ = cj.get("roofline") or {}
+                cb_ = cj.get("cpu_baseline") or {}
+                osf_ = (cj.get("operator_surface") or {})
+                shipped_out[wname] = dict(
+                    value=cj["value"], unit=cj["unit"], ms_per_step=cj["ms_per_step"], steps=cj["steps"], data=cj["data"],
+                    config={k_: cj["config"][k_] for k_ in ("tables", "divisions", "m", "lambda", "probes", "hard_cap", "B", "k", "queries_per_step", "pipeline")},
+                    recall_at_k=cj.get("recall_at_k"),
+                    scan=dict(kernel=rf_.get("kernel"), frac=rf_.get("frac"), achieved=rf_.get("achieved"), avg_launch_ms=rf_.get("avg_launch_ms"),
+                              launches=rf_.get("launches"), algorithmic_bytes_per_launch=rf_.get("algorithmic_bytes_per_launch")),
+                    stages_ms=st_, route_share_of_serial_step=round((st_.get("route_select") or 0.0) / tot_, 3),
+                    cpu_baseline=dict(value=cb_.get("value"), unit=cb_.get("unit"), cores=cb_.get("cores"), kind=cb_.get("kind"), sample=cb_.get("sample"),
+                                      matches_gpu=cb_.get("matches_gpu")),
+                    operator_surface_per_query_us=(osf_.get("per_query") or {}).get("route_plus_refine"),
+                    treeified=cj.get("treeified"), wall_s=round(time.perf_counter() - t_c, 1))
+            except Exception as e:      # a report beside the line, never a reason to lose it
+                shipped_out[wname] = dict(error=str(e)[:300])
+        extra = dict(shipped_profiles=shipped_out,
+                     note="the reference's shipped SIFT1M profiles run by this same command as child processes (full select + chunked scan + "
+                          "merge, three kernels per step on three contexts); `value` above is untouched by them")
+
     if rank == 0:
         out = {
             "metric": (("queries/sec @ recall@%d, SIFT-1M-shaped synthetic data d=%d B=%d" % (k, d, B)) if args.data in ("gaussian", "clustered")
@@ -1158,8 +1325,10 @@ def main():
             "route_stage": route_info,
             "variants": variants or None,
             "end_to_end": end_to_end,
+            "operator_surface": operator_surface,
             "timed_check": timed_check,
             "cpu_baseline": cpu,
+            "extra": extra,
         }
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
