@@ -354,6 +354,7 @@ struct RoutePlan {
     bool long_lists;
     int lazy, lazy_cap, lz_ht_size, lz_grid, lz_entries;
     bool bincheck;                 // the bounded select runs its exact treeify check (bin16)
+    int slice_bits, slice_ht;      // sliced hash build of the full select in global-arena mode (0 / 0: off)
     size_t lz_lds_bytes, small_bytes;
 };
 
@@ -408,6 +409,17 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
         if (static_cast<size_t>(pl.ht_size) <= words_max) want = std::max<size_t>(want, pl.ht_size);     // ... and the hash table itself, if it fits (route.hip.h)
         pl.lds_sort_words = static_cast<int>(std::min(words_max, std::max<size_t>(16384, want)));
     }
+    // Global-arena mode: the hash is built slice by slice of the id space in that LDS region (route.hip.h, B1): as many slices as keep
+    // a slice's table at most ~5/8 full (SIFT_P10_HIGH: 35 840 tuples, two slices of a 32 768-slot table; SIFT_P4_FAST: one)
+    pl.slice_bits = 0; pl.slice_ht = 0;
+    if (!pl.lds_mode && pl.lds_sort_words >= 4096 && pl.lds_sort_words < pl.ht_size && c->knob_slice) {   // (a table that fits the region is built there as it is)
+        int hs = 4096;
+        while (hs * 2 <= pl.lds_sort_words) hs <<= 1;
+        int kb = 0;
+        while (kb < 3 && (static_cast<int64_t>(pl.max_tuples) >> kb) * 8 > static_cast<int64_t>(hs) * 5) kb++;
+        if ((static_cast<int64_t>(pl.max_tuples) >> kb) * 8 <= static_cast<int64_t>(hs) * 5 || kb > 0) { pl.slice_bits = kb; pl.slice_ht = hs; }
+    }
+    if (pl.slice_ht > 0) pl.arena_bytes = (arena(pl.sort_cap) + static_cast<size_t>(pl.max_tuples) * 4 + 255) & ~size_t(255);   // + fseq (route.hip.h)
     pl.lds_bytes = pl.lds_mode ? pl.arena_bytes + small : small + static_cast<size_t>(pl.lds_sort_words) * 4 + 16;
     const int per_cu = std::max<int>(1, static_cast<int>(static_cast<size_t>(c->lds_limit) / (pl.lds_bytes + 512)));
     int wgs_per_cu = std::min(per_cu, 4);
@@ -659,6 +671,8 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_probe_dir = env_int("FSPANN_ROUTE_DIR", 1) != 0;
         c->knob_lazy_small = env_int("FSPANN_ROUTE_LAZY_SMALL", 1) != 0;
         c->knob_bincheck = env_int("FSPANN_ROUTE_BINCHECK", -1);
+        c->knob_slice = env_int("FSPANN_ROUTE_SLICE", 1) != 0;
+        c->knob_devflags = env_int("FSPANN_ROUTE_DEVFLAGS", 0);
         c->knob_dir_extra_bits = env_int("FSPANN_ROUTE_DIR_EXTRA_BITS", kDirBitsAuto);   // unset: as many as fit 64 MB (at most six)
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);
         c->knob_refine_stream = std::min(4, std::max(-1, env_int("FSPANN_REFINE_STREAM", -1)));   // -1: 4 per CU dense, 3 per CU gather
@@ -1189,6 +1203,7 @@ int prepare_route(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int prob
     p.g_sub = su_g ? reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->ws_route.p) + ((so_g + 255) & ~size_t(255)) + ((ar_g + 255) & ~size_t(255))) : nullptr;
     p.g_sub_stride = pl.maxcand;
     p.lds_sort_words = pl.lds_sort_words;
+    p.slice_bits = pl.slice_bits; p.slice_ht = pl.slice_ht; p.dev_flags = c->knob_devflags;
     p.wave_sort = c->knob_wave_sort > 0 ? 1 : 0;
     if (c->knob_wave_sort < 0) p.g_sub = nullptr;
     p.dbg = c->dbg_route;
@@ -1598,6 +1613,7 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
         pX.g_stride = static_cast<int64_t>(arena);
         pX.qcount = nullptr; pX.qlist = nullptr;
         pX.g_sub = nullptr; pX.lds_sort_words = 0;      // (limit <= 512 here: the long-list ordering is never reached)
+        pX.slice_ht = 0; pX.slice_bits = 0;              // (no LDS region behind the small arrays here: the arena table)
     }
 
     // ---- can the three roles share one kernel?

@@ -63,6 +63,9 @@ struct RouteParams {
     uint32_t* g_sub;               // long lists: (bucket | seq) sub-keys grouped by score (per block g_sub_stride u32), may be null
     int64_t g_sub_stride;
     int lds_sort_words;            // !kLds: u32 words of LDS behind the small arrays for sorting one score group (kLds: the hash table's)
+    int dev_flags;                 // FSPANN_ROUTE_DEVFLAGS (dev A/B): 2 = no nibble-counter treeify check
+    int slice_bits, slice_ht;      // !kLds: the hash is built in 2^slice_bits passes over slices of the id space, each in an LDS table of
+                                   //   slice_ht slots (a power of two <= lds_sort_words); slice_ht == 0: one table in the arena / LDS
     int wave_sort;                 // 1: groups are sorted by single waves on their own LDS slices (0: by the whole workgroup, one by one)
     int64_t out_cap;
     int32_t* out_ids;
@@ -421,6 +424,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
     uint32_t* ht = reinterpret_cast<uint32_t*>(arena + o);       o += static_cast<size_t>(prm.ht_size) * 4;
     int32_t* tup = reinterpret_cast<int32_t*>(arena + o);        o += static_cast<size_t>(prm.max_tuples) * 4;
     uint16_t* tscore = reinterpret_cast<uint16_t*>(arena + o);   o += (static_cast<size_t>(prm.max_tuples) * 2 + 15) & ~size_t(15);
+    int32_t* fseq = kLds ? nullptr : reinterpret_cast<int32_t*>(arena + o);   // sliced build: tuple of the FIRST occurrence of a repeat's id
     // small arrays always live in LDS
     unsigned char* sm = kLds ? smem + o : smem;
     size_t so = 0;
@@ -441,6 +445,13 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
     }
 
     __shared__ int s_n, s_raw, s_fill, s_cut, s_star, s_need, s_b1, s_lvl1, s_ndup, s_tree, s_suspect;
+    __shared__ int s_slice[8];                  // sliced build: live tuples per slice of the id space
+    // Sliced build (global-arena mode, long lists): the hash of ONE slice of the id space at a time, in the LDS region behind the
+    // small arrays.  Random CAS / min on a 256 KB table in global memory were a third of the full select at SIFT_P10_HIGH
+    // (494 us of a 1.48 ms workgroup, profiles/notes/r03_full_select_phases.txt); the tuples themselves are walked in order.
+    bool sliced = false;
+    uint32_t* const lds_region = reinterpret_cast<uint32_t*>(sm + ((so + static_cast<size_t>(TD) * 4 + 15) & ~size_t(15)));
+    auto slice_of = [&](int32_t id) -> int { return prm.slice_bits > 0 ? static_cast<int>((static_cast<uint32_t>(id) * 0xC2B2AE35u) >> (32 - prm.slice_bits)) : 0; };
 
     const uint32_t ht_mask = static_cast<uint32_t>(prm.ht_size - 1);
 
@@ -489,6 +500,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             for (int i = tid; i < TP; i += nthreads) { stepcnt[i] = 0; probe[i] = probe_q[i]; }
             for (int i = tid; i < TD; i += nthreads) { dupcnt[i] = 0; nprobe[i] = nprobe_q[i]; }
             if (tid == 0) { s_n = 0; s_raw = 0; s_fill = 0; s_cut = 0x7FFFFFFF; s_ndup = 0; s_lvl1 = 0; s_tree = 0; s_suspect = 0; }
+            if (tid < 8) s_slice[tid] = 0;
         }
         __syncthreads();
         FSP_STAMP(1);
@@ -528,16 +540,104 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                     // histogram of (presumed) first occurrences + live tuples per probe step: one atomic per wave
                     const int c1 = __popcll(__ballot(id >= 0));
                     if (lane == 0 && c1) { atomicAdd(&bins[sc], c1); atomicAdd(&stepcnt[ts], c1); }
+                    if constexpr (!kLds) {
+                        if (prm.slice_ht > 0 && prm.slice_bits > 0) {
+                            for (int sl = 0; sl < (1 << prm.slice_bits); sl++) {     // wave-uniform trips
+                                const int cs = __popcll(__ballot(id >= 0 && slice_of(id) == sl));
+                                if (lane == 0 && cs) atomicAdd(&s_slice[sl], cs);
+                            }
+                        }
+                    }
                 }
             }
         }
         __syncthreads();
         FSP_STAMP(8);
+        if constexpr (!kLds) {
+            if (prm.slice_ht > 0) {
+                // every slice must leave room in its table (ids are spread by a multiplicative hash: a slice beyond 7/8 of the
+                // table means crafted ids -> the arena table below)
+                sliced = true;
+                for (int sl = 0; sl < (1 << max(prm.slice_bits, 0)); sl++) sliced = sliced && (prm.slice_bits <= 0 || s_slice[sl] <= prm.slice_ht - (prm.slice_ht >> 3));
+                if (prm.slice_bits <= 0) sliced = prm.max_tuples <= prm.slice_ht - (prm.slice_ht >> 3);
+            }
+            if (sliced) {
+                const int hs = prm.slice_ht;
+                const uint32_t hmask = static_cast<uint32_t>(hs - 1);
+                const int hshift = 32 - (31 - __clz(hs));
+                uint32_t* sht = lds_region;
+                for (int sl = 0; sl < (1 << max(prm.slice_bits, 0)); sl++) {
+                    {
+                        uint4* h4 = reinterpret_cast<uint4*>(sht);
+                        const uint4 e4 = make_uint4(kHtEmpty, kHtEmpty, kHtEmpty, kHtEmpty);
+                        for (int i = tid; i < hs / 4; i += nthreads) h4[i] = e4;
+                    }
+                    __syncthreads();
+                    // pass 1: sht[slot of id] = min seq over the tuples holding id (tag | seq entries, as below).  The ids of kSlU trips
+                    // are requested together: one global round trip per kSlU tuples of a lane instead of one per tuple (one workgroup
+                    // per CU here: nothing else hides that latency)
+                    constexpr int kSlU = 8;
+                    for (int j0 = tid; j0 < prm.max_tuples; j0 += nthreads * kSlU) {
+                      int32_t idb[kSlU];
+#pragma unroll
+                      for (int u = 0; u < kSlU; u++) { const int j = j0 + u * nthreads; idb[u] = (j < prm.max_tuples) ? tup[j] : -1; }
+#pragma unroll
+                      for (int u = 0; u < kSlU; u++) {
+                        const int j = j0 + u * nthreads;
+                        const int32_t id = idb[u];
+                        if (id < 0 || slice_of(id) != sl) continue;
+                        uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> hshift;
+                        const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> hshift) | 1u;
+                        const uint32_t mytag = id_tag(id);
+                        const uint32_t val = (mytag << prm.seq_bits) | static_cast<uint32_t>(j);
+                        for (int tries = 0; tries < hs; tries++) {       // the table has room (checked above): an empty slot or the id is met
+                            const uint32_t cur = atomicCAS(&sht[slot], kHtEmpty, val);
+                            if (cur == kHtEmpty) break;
+                            if ((cur >> prm.seq_bits) == mytag && tup[cur & seq_mask] == id) { atomicMin(&sht[slot], val); break; }
+                            slot = (slot + stp) & hmask;
+                        }
+                      }
+                    }
+                    __syncthreads();
+                    // pass 2: every tuple of the slice looks its id up: the entry holds the FIRST tuple of the id; any other is a repeat
+                    for (int j0 = tid; j0 < prm.max_tuples; j0 += nthreads * kSlU) {
+                      int32_t idb[kSlU];
+#pragma unroll
+                      for (int u = 0; u < kSlU; u++) { const int j = j0 + u * nthreads; idb[u] = (j < prm.max_tuples) ? tup[j] : -1; }
+#pragma unroll
+                      for (int u = 0; u < kSlU; u++) {
+                        const int j = j0 + u * nthreads;
+                        const int32_t id = idb[u];
+                        if (id < 0 || slice_of(id) != sl) continue;
+                        uint32_t slot = (static_cast<uint32_t>(id) * 2654435761u) >> hshift;
+                        const uint32_t stp = ((static_cast<uint32_t>(id) * 0x85EBCA6Bu) >> hshift) | 1u;
+                        const uint32_t mytag = id_tag(id);
+                        int f = j;
+                        for (int tries = 0; tries < hs; tries++) {
+                            const uint32_t cur = sht[slot];
+                            if (cur != kHtEmpty && (cur >> prm.seq_bits) == mytag && tup[cur & seq_mask] == id) { f = static_cast<int>(cur & seq_mask); break; }
+                            slot = (slot + stp) & hmask;
+                        }
+                        if (f != j) {
+                            const uint16_t v = tscore[j];
+                            tscore[j] = v & ~kFirstFlag;
+                            fseq[j] = f;
+                            const int ts = FSP_TS(j);
+                            atomicSub(&bins[v & 0x3FFF], 1);
+                            atomicSub(&stepcnt[ts], 1);
+                            atomicAdd(&dupcnt[ts / P], 1);
+                        }
+                      }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
         // ---- B1: hash build, ht[slot] = min seq of the id owning the slot.  Every lane walks ITS OWN queue of
         // tuples (j = tid, tid + nthreads, ...) one probe step per loop trip, so a lane with a long probe
         // sequence does not stall the other 63: the wave finishes after max-over-lanes of the SUM of probe
         // lengths instead of the sum of per-tuple maxima.
-        {
+        if (!sliced) {
             int j = tid;
             int32_t id = -1;
             uint32_t slot = 0, stp = 1, mytag = 0;
@@ -571,8 +671,9 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
 
         const int ndup = s_ndup;
         // ---- repeats: drop them from "first" bookkeeping -----------------------------------------
-        // (list path when they fit; otherwise recompute the flags from the hash slots)
-        if (ndup <= kDupListMax) {
+        // (list path when they fit; otherwise recompute the flags from the hash slots; the sliced build has done it already)
+        if (sliced) {
+        } else if (ndup <= kDupListMax) {
             for (int l = tid; l < ndup; l += nthreads) {
                 const int j = duplist[l];
                 const uint16_t v = tscore[j];
@@ -636,7 +737,28 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
         FSP_STAMP(9);
 
         // ---- B3: repeated occurrences: min score + strict improvements in table order (PIS:744-750) --
-        if (ndup > 0 && ndup <= kDupListMax) {
+        if (sliced) {
+            for (int td = 0; td < TD; td++) {   // table phases (an id occurs at most once per table); the first occurrence comes from fseq
+                if (dupcnt[td] == 0) continue;  // uniform
+                int improved = 0;
+                const int j1 = (td * P + nprobe[td]) * S;
+                for (int j = td * P * S + tid; j < j1; j += nthreads) {
+                    const uint16_t v = tscore[j];
+                    if (!(v & kLiveFlag) || (v & kFirstFlag)) continue;
+                    const int f = fseq[j];
+                    const int sc = probe[FSP_TS(j)].y;
+                    const int old = tscore[f] & 0x3FFF;
+                    if (sc < old) {
+                        tscore[f] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
+                        atomicSub(&bins[old], 1);
+                        atomicAdd(&bins[sc], 1);
+                        improved++;
+                    }
+                }
+                if (improved) atomicAdd(&s_raw, improved);
+                __syncthreads();
+            }
+        } else if (ndup > 0 && ndup <= kDupListMax) {
             // all repeats in parallel: a repeat d improves iff its score is below the first occurrence's
             // and below every earlier repeat of the same id; the overall minimum (earliest on ties) is
             // the one that rewrites the entry's score.
@@ -743,15 +865,28 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
         FSP_STAMP(11);
         // compaction of the surviving candidates: score < star, or score == star && bucket bin <= b1
         uint64_t* gs = prm.g_sort ? prm.g_sort + static_cast<int64_t>(block_id) * prm.g_sort_stride : sortbuf;
-        for (int j0 = 0; j0 < prm.max_tuples; j0 += nthreads) {     // uniform trip count: the ballots below need every lane
+        constexpr int kCmU = 4;                                      // trips whose tuple words are requested together (global-arena mode: one
+        for (int jb = 0; jb < prm.max_tuples; jb += nthreads * kCmU) {   //   round trip per kCmU trips; uniform trip counts: the ballots need every lane)
+          uint16_t vb[kCmU];
+          int32_t ib[kCmU];
+#pragma unroll
+          for (int u = 0; u < kCmU; u++) {
+              const int j = jb + u * nthreads + tid;
+              vb[u] = (j < prm.max_tuples) ? tscore[j] : static_cast<uint16_t>(0);
+              ib[u] = (j < prm.max_tuples) ? tup[j] : -1;
+          }
+#pragma unroll
+          for (int u = 0; u < kCmU; u++) {
+            const int j0 = jb + u * nthreads;
+            if (j0 >= prm.max_tuples) break;                           // uniform
             const int j = j0 + tid;
             bool take = false;
             uint64_t key = 0;
             if (j < prm.max_tuples) {
-                const uint16_t v = tscore[j];
+                const uint16_t v = vb[u];
                 const int sc = v & 0x3FFFu;
                 if ((v & kFirstFlag) && sc <= star) {
-                    const uint32_t bfield = bucket_field(tup[j]);
+                    const uint32_t bfield = bucket_field(ib[u]);
                     if (!(sc == star && lvl1 && static_cast<int>(bfield >> (kBucketBits - 10)) > b1)) {
                         take = true;
                         key = (static_cast<uint64_t>(sc) << (kBucketBits + kSeqBits)) |
@@ -771,6 +906,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 if (pos < prm.sort_cap) sortbuf[pos] = key;
                 else gs[pos] = key;  // only reachable when g_sort exists (host guarantees capacity)
             }
+          }
         }
         __syncthreads();
         FSP_STAMP(4);
@@ -828,10 +964,10 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             // costs no global round trip (one per group and wave was most of what was left of the ordering at SIFT_P4_FAST).
             int wcap = 64;                                   // entries one wave can sort in its slice (a power of two)
             const bool sub_lds = nwv * 64 + nsel <= gcap_all - 1024;
-            const int room = sub_lds ? gcap_all - 1024 - nsel : gcap_all - 1024;
+            const int room = sub_lds ? ((gcap_all - 1024 - nsel) & ~3) : gcap_all - 1024;
             while (wcap * 2 * nwv <= room && wcap < 4096) wcap <<= 1;
             if (!prm.wave_sort) wcap = 0;
-            uint32_t* gsub = sub_lds ? gsort + (gcap_all - 1024 - nsel) : prm.g_sub + static_cast<int64_t>(block_id) * prm.g_sub_stride;
+            uint32_t* gsub = sub_lds ? gsort + ((gcap_all - 1024 - nsel) & ~3) : prm.g_sub + static_cast<int64_t>(block_id) * prm.g_sub_stride;
             __syncthreads();                                 // ht, bins: every wave is past their last use
             for (int i = tid; i < ngrp; i += nthreads) bins[i] = 0;
             if (tid == 0) s_cut = 0;                         // s_cut: a group did not fit a wave's slice
@@ -978,19 +1114,121 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 return h ^ (h >> 16);
             };
             __syncthreads();       // ht, tscore: every wave is past its last use
-            {
+            // Direct 4-bit counters, one per bin of the stage's table, in LDS (cap / 8 words: 16 KB for 32 768 bins): an increment
+            // that finds eight is the ninth node of its bin — exact, no hash, no second look.  (A counter passes nine before it can
+            // wrap, and a wrap only carries into its neighbour, so nothing is flagged that has not been flagged already.)  This is what
+            // the long lists of the shipped profiles use — bestScore resizes there (n > 0.75 cap0), and the (bin -> count) hash in the
+            // global arena was 228 us of a 1.48 ms workgroup at SIFT_P10_HIGH.
+            uint32_t* nib = kLds ? ht : lds_region;
+            const int nib_words = kLds ? prm.ht_size : prm.lds_sort_words;
+            const bool use_nib = capf >= 64 && (capf >> 3) <= nib_words && !(prm.dev_flags & 2);
+            if (use_nib) {
+                if (!single && wave == 0) {     // exclusive prefix of stepcnt over the steps that ran (insertion ranks, as below)
+                    int carry = 0;
+                    for (int g0 = 0; g0 < TP; g0 += 64) {
+                        const int g = g0 + lane;
+                        const int v = (g < TP && g <= cut) ? stepcnt[g] : 0;
+                        int incl = v;
+                        for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off); if (lane >= off) incl += u; }
+                        if (g < TP) stepcnt[g] = carry + incl - v;
+                        carry += __shfl(incl, 63);
+                    }
+                }
+                const int SPt = (S + 63) >> 6, nwv = nthreads >> 6;
+                int capk = prm.cap0;
+                long long thrk = thr0;
+                for (int stage = 0; stage < 24; stage++) {
+                    const long long endk = (thrk < static_cast<long long>(n) - 1) ? thrk : static_cast<long long>(n) - 1;   // last rank of this stage
+                    __syncthreads();
+                    for (int i = tid; i < (capk >> 3); i += nthreads) nib[i] = 0u;
+                    __syncthreads();
+                    bool hit = false;
+                    if (single) {
+                        constexpr int kTU = 4;
+                        for (int j0 = tid; j0 < prm.max_tuples; j0 += nthreads * kTU) {
+                            uint16_t vb[kTU];
+                            int32_t ib[kTU];
+#pragma unroll
+                            for (int u = 0; u < kTU; u++) {
+                                const int j = j0 + u * nthreads;
+                                vb[u] = (j < prm.max_tuples) ? tscore[j] : static_cast<uint16_t>(0);
+                                ib[u] = (j < prm.max_tuples) ? tup[j] : -1;
+                            }
+#pragma unroll
+                            for (int u = 0; u < kTU; u++) {
+                                if (!(vb[u] & kFirstFlag)) continue;
+                                const uint32_t b = spread_of(ib[u]) & static_cast<uint32_t>(capk - 1);
+                                const uint32_t sh = (b & 7u) * 4u;
+                                hit = hit || (((atomicAdd(&nib[b >> 3], 1u << sh) >> sh) & 15u) >= 8u);
+                            }
+                        }
+                    } else if (SPt == 1) {
+                        // (one 64-id piece per probe step: the tuple words of four steps of a wave are requested together)
+                        constexpr int kTU = 4;
+                        for (int ts0 = wave; ts0 < TP; ts0 += nwv * kTU) {      // wave-uniform: the ballots need every lane
+                            if (ts0 > cut) break;
+                            uint16_t vb[kTU];
+                            int32_t ib[kTU];
+#pragma unroll
+                            for (int u = 0; u < kTU; u++) {
+                                const int ts = ts0 + u * nwv;
+                                const bool in = ts < TP && ts <= cut && lane < S;
+                                vb[u] = in ? tscore[ts * S + lane] : static_cast<uint16_t>(0);
+                                ib[u] = in ? tup[ts * S + lane] : -1;
+                            }
+#pragma unroll
+                            for (int u = 0; u < kTU; u++) {
+                                const int ts = ts0 + u * nwv;
+                                if (ts >= TP || ts > cut) break;                 // wave-uniform
+                                const bool f = (vb[u] & kFirstFlag) != 0;
+                                const unsigned long long bm = __ballot(f);
+                                const int rank = stepcnt[ts] + __popcll(bm & ((1ull << lane) - 1ull));
+                                if (!f || rank > endk) continue;
+                                const uint32_t b = spread_of(ib[u]) & static_cast<uint32_t>(capk - 1);
+                                const uint32_t sh = (b & 7u) * 4u;
+                                hit = hit || (((atomicAdd(&nib[b >> 3], 1u << sh) >> sh) & 15u) >= 8u);
+                            }
+                        }
+                    } else {
+                        for (int ts = wave; ts < TP; ts += nwv) {          // wave-uniform: the ballots need every lane
+                            if (ts > cut) break;
+                            int carry = stepcnt[ts];
+                            for (int pc = 0; pc < SPt; pc++) {
+                                const int pos = pc * 64 + lane;
+                                const int j = ts * S + pos;
+                                const bool f = (pos < S) && (tscore[j] & kFirstFlag);
+                                const unsigned long long bm = __ballot(f);
+                                const int rank = carry + __popcll(bm & ((1ull << lane) - 1ull));
+                                carry += __popcll(bm);
+                                if (!f || rank > endk) continue;
+                                const uint32_t b = spread_of(tup[j]) & static_cast<uint32_t>(capk - 1);
+                                const uint32_t sh = (b & 7u) * 4u;
+                                hit = hit || (((atomicAdd(&nib[b >> 3], 1u << sh) >> sh) & 15u) >= 8u);
+                            }
+                        }
+                    }
+                    if (hit) s_tree = 1;
+                    __syncthreads();
+                    if (s_tree || thrk >= static_cast<long long>(n) - 1) break;     // block-uniform
+                    capk <<= 1;
+                    thrk <<= 1;
+                    if (capk > capf) break;                                        // (n <= thr of the final table: not reached)
+                }
+            }
+            if (!use_nib) {
                 uint4* h4 = reinterpret_cast<uint4*>(ht);
                 for (int i = tid; i < prm.ht_size / 4; i += nthreads) h4[i] = make_uint4(0, 0, 0, 0);
             }
             __syncthreads();
-            for (int j = tid; j < prm.max_tuples; j += nthreads) {
+            if (!use_nib) for (int j = tid; j < prm.max_tuples; j += nthreads) {
                 if (!(tscore[j] & kFirstFlag)) continue;
                 const uint32_t b0 = spread_of(tup[j]) & static_cast<uint32_t>(prm.cap0 - 1);
                 if (atomicAdd(&ht[b0 & ht_mask], 1u) >= 8u) s_suspect = 1;
             }
             __syncthreads();
             const bool exact0 = single && prm.ht_size >= prm.cap0;   // no folding, one stage: the counters ARE the bins
-            if (s_suspect && exact0) { if (tid == 0) s_tree = 1; }
+            if (use_nib) { }
+            else if (s_suspect && exact0) { if (tid == 0) s_tree = 1; }
             else if (s_suspect) {
                 // exact pass.  Insertion rank of a first occurrence = distinct ids of earlier probe steps + earlier first
                 // occurrences inside its own step (tuples of a step are laid out in insertion order).

@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g  # noqa: E402
 
 pkg = g.load_package()
+if os.environ.get('AB_LIB'):
+    pkg._native._SO = os.path.abspath(os.environ['AB_LIB'])   # a variant build (debug stamps)
 L = pkg._native.lib()
 HAVE_STAMPS = hasattr(L, "fspann_debug_route_stamps")      # only in FSPANN_BUILD_DEBUG=1 builds; a release build still prints the timing
 if HAVE_STAMPS:
