@@ -472,7 +472,28 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     const int nchunks = static_cast<int>((B + kRefRows - 1) / kRefRows);
     RefinePartial* partial = nullptr;
     int32_t* pcnt = nullptr;
-    if (nchunks > 1) {
+    // Long candidate lists (B in the thousands, k = 100: the reference's shipped profiles): a workgroup walks a RUN of consecutive
+    // chunks of one query and keeps its best k in LDS (refine_topk_running) — one list per run instead of one per chunk.  With at
+    // least half a grid of queries a run is the whole query (no merge kernel at all); fewer queries are cut into as many runs as
+    // fill the grid (one query: one chunk per workgroup, as before).
+    const int stream_wgs_m = (c->knob_refine_stream >= 0) ? std::min(c->knob_refine_stream, 4) : 4;
+    int npieces = 0, cpp = 0;
+    if (!GATHER && nchunks > 1 && k > kRefFilterMaxK && k <= kRunMaxK && c->knob_refine_run && stream_wgs_m > 0 && DC * sizeof(TC) == 128 &&
+        (d % VN == 0) && ((reinterpret_cast<uintptr_t>(cand) & 15) == 0) && nq * nchunks < (int64_t(1) << 31)) {   // (= the streaming scan will run)
+        const int64_t slots = static_cast<int64_t>(c->num_cus) * stream_wgs_m;
+        int np = (nq * 2 >= slots) ? 1 : static_cast<int>(std::min<int64_t>(nchunks, (slots + nq - 1) / std::max<int64_t>(nq, 1)));
+        cpp = (nchunks + np - 1) / np;
+        npieces = (nchunks + cpp - 1) / cpp;
+        if (nq * npieces >= (int64_t(1) << 31)) { npieces = 0; cpp = 0; }
+    }
+    if (npieces > 1) {
+        const size_t pb = static_cast<size_t>(nq) * npieces * k * sizeof(RefinePartial);
+        const size_t cb = static_cast<size_t>(nq) * npieces * 2 * 4;
+        int rc = ensure(c, c->ws_refine, pb + cb + 64);
+        if (rc) return rc;
+        partial = static_cast<RefinePartial*>(c->ws_refine.p);
+        pcnt = reinterpret_cast<int32_t*>(static_cast<char*>(c->ws_refine.p) + ((pb + 15) & ~size_t(15)));
+    } else if (nchunks > 1 && npieces == 0) {
         const size_t pb = static_cast<size_t>(nq) * nchunks * k * sizeof(RefinePartial);
         const size_t cb = static_cast<size_t>(nq) * nchunks * 2 * 4;
         int rc = ensure(c, c->ws_refine, pb + cb + 64);
@@ -483,7 +504,7 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     const bool vec = (d % VN == 0) && ((reinterpret_cast<uintptr_t>(cand) & 15) == 0);
     const size_t lds = std::max<size_t>(static_cast<size_t>(kRefRows) * (vec ? DC + VN : DC + 1) * sizeof(TC), static_cast<size_t>(kRefRows) * 16);
     const unsigned grid = static_cast<unsigned>(nq * nchunks);
-    const RefineArgs<TC, TQ> ra{q, cand, GATHER ? c->store_n : 0, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt, c->dbg_route};
+    const RefineArgs<TC, TQ> ra{q, cand, GATHER ? c->store_n : 0, B, d, cand_ids, cand_count, k, nchunks, out_ids, out_dist, out_count, scored, partial, pcnt, npieces, cpp, c->dbg_route};
     auto launch = [&](auto kern) -> int {
         if (lds > 64 * 1024) FSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         if (c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size()) {   // start/stop events attached to this very dispatch
@@ -502,7 +523,7 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     if constexpr (DC * sizeof(TC) == 128) if (vec && stream_wgs > 0 && nq * nchunks < (int64_t(1) << 31)) {
         // the scan as a stream: knob_refine_stream workgroups per CU, each walking several (query, chunk) units with the loads
         // of the next tile in flight across unit boundaries (refine_stream_run)
-        const int64_t units = nq * nchunks;
+        const int64_t units = npieces > 0 ? nq * npieces : nq * nchunks;
         const unsigned sgrid = static_cast<unsigned>(std::min<int64_t>(units, static_cast<int64_t>(c->num_cus) * stream_wgs));
         const bool timed = c->rt_on && (c->rt_seen++ % c->rt_every) == 0 && c->rt_used + 2 <= c->rt_events.size();
         hipEvent_t ev0 = timed ? c->rt_events[c->rt_used] : nullptr, ev1 = timed ? c->rt_events[c->rt_used + 1] : nullptr;
@@ -525,6 +546,16 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
             }
         }
         if (!fixed) {
+            if constexpr (!GATHER) {
+                if (npieces > 0) {
+                    auto kern = refine_stream_kernel<TC, TQ, DC, false, true>;
+                    if (timed) hipExtLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, ev0, ev1, 0, ra, nq);
+                    else hipLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, ra, nq);
+                    fixed = true;
+                }
+            }
+        }
+        if (!fixed) {
             auto kern = refine_stream_kernel<TC, TQ, DC, GATHER>;
             if (timed) hipExtLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, ev0, ev1, 0, ra, nq);
             else hipLaunchKernelGGL(kern, dim3(sgrid), dim3(kRefRows), lds, c->stream, ra, nq);
@@ -534,7 +565,10 @@ int launch_refine_dc(fspann_ctx* c, int64_t nq, const TQ* q, const TC* cand, int
     if (!streamed) lrc = vec ? launch(refine_scan_kernel<TC, TQ, DC, true, GATHER>) : launch(refine_scan_kernel<TC, TQ, DC, false, GATHER>);
     if (lrc) return lrc;
     FSP_HIP(hipGetLastError());
-    if (nchunks > 1) {
+    if (npieces > 0 && !streamed) return fail(FSPANN_E_STATE, "refine: the running top-k was planned but the streaming scan did not run");
+    const int nlists = npieces > 0 ? npieces : nchunks;      // partial lists per query (runs of chunks, or chunks)
+    if (nlists > 1) {
+        const int nchunks = nlists;                          // (the merge below: one list per run)
         // all keys of a query's partial lists in LDS when they fit (two workgroups per CU at least)
         const size_t mlds = static_cast<size_t>(nchunks) * k * 8 + static_cast<size_t>(nchunks) * 4 + 16;
         if (mlds <= 72 * 1024) {
@@ -672,6 +706,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_lazy_small = env_int("FSPANN_ROUTE_LAZY_SMALL", 1) != 0;
         c->knob_bincheck = env_int("FSPANN_ROUTE_BINCHECK", -1);
         c->knob_slice = env_int("FSPANN_ROUTE_SLICE", 1) != 0;
+        c->knob_refine_run = env_int("FSPANN_REFINE_RUN", 1) != 0;
         c->knob_devflags = env_int("FSPANN_ROUTE_DEVFLAGS", 0);
         c->knob_dir_extra_bits = env_int("FSPANN_ROUTE_DIR_EXTRA_BITS", kDirBitsAuto);   // unset: as many as fit 64 MB (at most six)
         c->knob_refine_dc = env_int("FSPANN_REFINE_DC", 0);

@@ -92,6 +92,8 @@ struct RefineArgs {
     int32_t* scored;
     RefinePartial* partial;
     int32_t* partial_cnt;
+    int npieces, cpp;            // running top-k (refine_topk_running): a query's chunks are cut into npieces runs of cpp consecutive chunks,
+                                 //   one workgroup walks a run and keeps its best k in LDS; 0 / 0: one partial list per chunk
     long long* dbg;              // FSPANN_DEBUG_STAMPS builds: [grid][4 waves][16] wall_clock64 stamps of each workgroup's first unit (else unused)
 };
 
@@ -287,6 +289,127 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
 #undef EM_STAMP
 }
 
+// Stage C for a RUN of consecutive chunks of one query walked by ONE workgroup (long candidate lists: B in the thousands, k = 100):
+// the best k of the chunks seen so far stay in LDS, sorted by (distance bits, candidate position); a chunk contributes only the
+// keys BELOW the current k-th (later positions lose ties) — a handful per chunk once the list has filled — and they are merged
+// by rank: an old entry moves up by the number of newcomers in front of it, a newcomer's place is its bound in the old list
+// plus the newcomers in front of it.  With one list per chunk (refine_topk_emit) SIFT_P10_HIGH wrote 86 lists of 100 per query,
+// ranked all 256 keys of every chunk against each other and merged the lists in a second kernel (0.33 ms per 1024 queries).
+// first / last: the run's first and last chunk; at `last` the list is written out — the final result when the run is the whole
+// query (npieces == 1: no merge kernel at all), else the partial list of piece `piece`.
+constexpr int kRunMaxK = 128;
+template <typename TC, typename TQ, int PITCH>
+__device__ __forceinline__ void refine_topk_running(const RefineArgs<TC, TQ>& a, TC* tile, const bool valid, const uint64_t key, const int32_t my_id,
+                                                    const int64_t qi, const int piece, const int pos, const bool first, const bool last) {
+    __shared__ uint4 s_best[kRunMaxK];             // (key lo, key hi, id, candidate position)
+    __shared__ int s_nbest, s_nvalid_run, s_wcnt[kRefRows / 64], s_wval[kRefRows / 64];
+    const int k = a.k;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr size_t kRegion = static_cast<size_t>(64) * PITCH * sizeof(TC);
+    static_assert(kRegion >= 64 * 16 && kRegion % 16 == 0, "a wave's tile rows hold its survivors");
+    auto wlist = [&](int w) { return reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(tile) + static_cast<size_t>(w) * kRegion); };
+    auto key_of = [](const uint4 e) { return static_cast<uint64_t>(e.x) | (static_cast<uint64_t>(e.y) << 32); };
+    const int L = first ? 0 : s_nbest;             // (the previous chunk's update is behind the unit-end barrier)
+    uint64_t thr = kInvalidKey;                    // list not full: every valid key enters (valid keys are finite: below all-ones)
+    if (L == k) thr = key_of(s_best[k - 1]);
+    const bool sv = valid && key < thr;            // strictly: an equal key at a later position ranks behind the k-th
+    const unsigned long long bm = __ballot(sv), bv = __ballot(valid);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();               // this wave's tile rows are dead (other waves may still be reading theirs)
+    if (sv) {
+        const int at = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bm), 0u)));
+        wlist(wave)[at] = make_uint4(static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), static_cast<uint32_t>(my_id), static_cast<uint32_t>(pos));
+    }
+    if (lane == 0) { s_wcnt[wave] = __popcll(bm); s_wval[wave] = __popcll(bv); }
+    __syncthreads();   // (1) survivors and counts of all waves
+    static_assert(kRefRows / 64 == 4, "four waves");
+    const int c0 = s_wcnt[0], c1 = s_wcnt[1], c2 = s_wcnt[2], c3 = s_wcnt[3];
+    const int S = c0 + c1 + c2 + c3;
+    const int nv = s_wval[0] + s_wval[1] + s_wval[2] + s_wval[3];
+    if (S > 0) {                                   // block-uniform
+        // every entry of old list + newcomers finds its place (at most two entries per thread: L <= 128, S <= 256)
+        uint4 me[2];
+        int rk[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+            const int t = tid + t2 * kRefRows;
+            if (t >= L + S) continue;
+            if (t < L) {
+                me[t2] = s_best[t];
+                const uint64_t mk = key_of(me[t2]);
+                int r = t;
+                for (int w = 0; w < 4; w++) {
+                    const int cw = s_wcnt[w];
+                    const uint4* wl = wlist(w);
+                    for (int j = 0; j < cw; j++) r += key_of(wl[j]) < mk;           // an old entry wins ties (earlier position)
+                }
+                rk[t2] = r;
+            } else {
+                int j = t - L, w = 0;
+                if (j >= c0) { j -= c0; w = 1; if (j >= c1) { j -= c1; w = 2; if (j >= c2) { j -= c2; w = 3; } } }
+                me[t2] = wlist(w)[j];
+                const uint64_t mk = key_of(me[t2]);
+                int lo = 0, hi = L;                                                 // old entries with key <= mine
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (key_of(s_best[mid]) <= mk) lo = mid + 1; else hi = mid; }
+                int r = lo;
+                for (int w2 = 0; w2 < 4; w2++) {
+                    const int cw = s_wcnt[w2];
+                    const uint4* wl = wlist(w2);
+                    for (int j2 = 0; j2 < cw; j2++) {
+                        const uint4 o = wl[j2];
+                        const uint64_t ok_ = key_of(o);
+                        r += (ok_ < mk) || (ok_ == mk && o.w < me[t2].w);
+                    }
+                }
+                rk[t2] = r;
+            }
+        }
+        __syncthreads();   // (2) every read of the old list and of the newcomers is done
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++)
+            if (rk[t2] < k) s_best[rk[t2]] = me[t2];
+    }
+    if (tid == 0) {
+        s_nbest = min(k, L + S);
+        s_nvalid_run = (first ? 0 : s_nvalid_run) + nv;
+    }
+    if (last) {
+        __syncthreads();   // (3) the list is complete
+        const int nb = s_nbest;
+        if (a.npieces == 1) {
+            for (int i = tid; i < k; i += kRefRows) {
+                if (i < nb) {
+                    const uint4 e = s_best[i];
+                    a.out_ids[qi * k + i] = static_cast<int32_t>(e.z);
+                    a.out_dist[qi * k + i] = __longlong_as_double(static_cast<long long>(key_of(e)));
+                } else {
+                    a.out_ids[qi * k + i] = -1;
+                    a.out_dist[qi * k + i] = __longlong_as_double(0x7FF0000000000000LL);
+                }
+            }
+            if (tid == 0) {
+                a.out_count[qi] = nb;
+                if (a.scored) a.scored[qi] = s_nvalid_run;
+            }
+        } else {
+            const int64_t li = qi * a.npieces + piece;
+            for (int i = tid; i < nb; i += kRefRows) {
+                const uint4 e = s_best[i];
+                RefinePartial pp;
+                pp.key = key_of(e);
+                pp.pos = static_cast<int32_t>(e.w);
+                pp.id = static_cast<int32_t>(e.z);
+                a.partial[li * k + i] = pp;
+            }
+            if (tid == 0) {
+                a.partial_cnt[li * 2 + 0] = nb;
+                a.partial_cnt[li * 2 + 1] = s_nvalid_run;
+            }
+        }
+    }
+}
+
 // One workgroup (kRefRows threads) = one 256-row chunk of one query: block `bidx` of nq * nchunks.  `smem` = dynamic LDS.
 template <typename TC, typename TQ, int DC, bool VEC, bool GATHER>
 __device__ __forceinline__ void refine_scan_block(const RefineArgs<TC, TQ>& a, unsigned char* smem, const int64_t bidx,
@@ -450,9 +573,12 @@ struct RefineNoFix {
     static constexpr bool enabled = false;
     __device__ __forceinline__ void operator()(int64_t) const {}
 };
-template <typename TC, typename TQ, int DC, bool GATHER, class FixFn = RefineNoFix>
+// kMulti (dense blocks, several chunks per query, 32 < k <= kRunMaxK): the workgroup's units are RUNS of consecutive chunks of one
+// query (item = query * npieces + piece, items wg, wg + nwg, ...; a.cpp chunks per run) and the top-K is refine_topk_running.
+template <typename TC, typename TQ, int DC, bool GATHER, class FixFn = RefineNoFix, bool kMulti = false>
 __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, unsigned char* smem, const int64_t wg, const int64_t nwg,
                                                   const int64_t nq, const bool counts_fresh, const FixFn fix = FixFn()) {
+    static_assert(!(kMulti && (GATHER || FixFn::enabled)), "runs of chunks: dense blocks, no hand-over");
     using V = typename VecOf<TC>::type;
     constexpr int VN = VecOf<TC>::N;
     constexpr int PITCH = DC + VN;
@@ -475,7 +601,19 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // a scalar: what derives from it is scalar work
     const int ntile = (d + DC - 1) / DC;
-    const int64_t nunits = nq * nchunks;
+    const int64_t nunits = kMulti ? nq * a.npieces : nq * nchunks;      // kMulti: ITEMS (runs of chunks)
+    // position in the workgroup's sequence of chunks (kMulti): run `item`, its query, first chunk and length, the chunk inside it
+    struct RunPos { int64_t item, qi; int cc, nch, chunk0; };
+    auto run_set = [&](RunPos& rp, const int64_t item) {
+        rp.item = item; rp.cc = 0;
+        const uint32_t it_ = static_cast<uint32_t>(min(item, nunits - 1));           // past the end: the last run's numbers (never consumed)
+        const uint32_t qq = it_ / static_cast<uint32_t>(a.npieces);
+        rp.qi = qq;
+        rp.chunk0 = static_cast<int>(it_ - qq * static_cast<uint32_t>(a.npieces)) * a.cpp;
+        rp.nch = min(a.cpp, nchunks - rp.chunk0);
+    };
+    RunPos ip{}, cp{};                                     // issue side, consume side
+    if constexpr (kMulti) { run_set(ip, wg); run_set(cp, wg); }
     const int slot_row = wave * 64 + lane / VPR;          // + i * (64 / VPR): row of this lane's i-th 16-byte slot
     const int slot_col = (lane % VPR) * VN;               // column of the slot inside a tile
 
@@ -518,13 +656,18 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     };
     auto unit_base = [&](const int64_t u) -> const TC* {
         if constexpr (GATHER) return cand;
+        if constexpr (kMulti) {
+            const int r0 = (ip.chunk0 + ip.cc) * kRefRows;
+            irows = static_cast<int>(min(static_cast<int64_t>(kRefRows), B - r0));
+            return cand + (ip.qi * B + r0) * static_cast<int64_t>(d);
+        }
         const int64_t uu = min(u, nunits - 1);
         int64_t qi; int r0;
         split_unit(uu, qi, r0);
         return cand + (qi * B + r0) * static_cast<int64_t>(d);
     };
     const TC* ibase = unit_base(iu);
-    load_sources(iu);
+    if constexpr (!kMulti) load_sources(iu);
     // Dense blocks are read through a BUFFER resource per unit (base = the unit's first row, extent = its rows): the address
     // of slot i is one 32-bit lane offset plus a wave-uniform scalar offset (no 64-bit address arithmetic, no address
     // registers per slot), and a slot beyond the unit's rows is answered with zeros by the range check instead of a clamp.
@@ -551,9 +694,14 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         }                                                                                                           \
         if (++it == ntile) {                                                                                        \
             it = 0;                                                                                                 \
-            iu += nwg;                                                                                              \
-            ibase = unit_base(iu);                                                                                  \
-            load_sources(iu);                                                                                       \
+            if constexpr (kMulti) {                                                                                 \
+                if (++ip.cc == ip.nch) { run_set(ip, ip.item + nwg); iu = ip.item; }                                \
+                ibase = unit_base(iu);                                                                              \
+            } else {                                                                                                \
+                iu += nwg;                                                                                          \
+                ibase = unit_base(iu);                                                                              \
+                load_sources(iu);                                                                                   \
+            }                                                                                                       \
             if constexpr (!GATHER) irsrc = unit_rsrc();                                                             \
         }                                                                                                           \
     } while (0)
@@ -597,9 +745,10 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
     }
 
     // ---- consume side ------------------------------------------------------------------------------------------------
-    for (int64_t u = wg; u < nunits; u += nwg) {
+    for (int64_t u = wg; u < nunits;) {
         int64_t qi; int r0;
-        split_unit(u, qi, r0);
+        if constexpr (kMulti) { qi = cp.qi; r0 = (cp.chunk0 + cp.cc) * kRefRows; }
+        else split_unit(u, qi, r0);
         const int chunk = r0 / kRefRows;
         // the query row through the CONSTANT address space: uniform loads from it are scalar loads whatever else the
         // enclosing kernel does (see encode_exact_block); the query batch is an input, nothing writes it
@@ -668,17 +817,23 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
         uint64_t key = kInvalidKey;
         if (valid) key = static_cast<uint64_t>(__double_as_longlong(sqrt(s)));  // QSI.java:371
         RS_STAMP(5);
+        if constexpr (kMulti) {
+            refine_topk_running<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, static_cast<int>(cp.item - qi * a.npieces), r0 + tid, cp.cc == 0, cp.cc == cp.nch - 1);
+        } else {
 #ifdef FSPANN_DEBUG_STAMPS
         refine_topk_emit<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, chunk, r0, (a.dbg && first_unit) ? a.dbg + (wg * 4 + wave) * 16 : nullptr);
 #else
         refine_topk_emit<TC, TQ, PITCH>(a, tile, valid, key, my_id, qi, chunk, r0);
 #endif
+        }
         RS_STAMP(12);
 #ifdef FSPANN_DEBUG_STAMPS
         if (a.dbg && lane == 0 && first_unit) { for (int i = 0; i <= 5; i++) a.dbg[(wg * 4 + wave) * 16 + i] = s_rs_stamps[wave][i]; a.dbg[(wg * 4 + wave) * 16 + 12] = s_rs_stamps[wave][12]; }
 #endif
         __syncthreads();       // every wave has finished reading the other waves' scratch before the tile is written again
         first_unit = false;
+        if constexpr (kMulti) { if (++cp.cc == cp.nch) { run_set(cp, cp.item + nwg); u = cp.item; } }
+        else u += nwg;
     }
 #undef RS_STAMP
 #undef FSP_STREAM_TILE
@@ -686,10 +841,10 @@ __device__ __forceinline__ void refine_stream_run(const RefineArgs<TC, TQ>& a, u
 #undef FSP_WAVE_SYNC
 }
 
-template <typename TC, typename TQ, int DC, bool GATHER>
+template <typename TC, typename TQ, int DC, bool GATHER, bool kMulti = false>
 __global__ __launch_bounds__(kRefRows, (GATHER ? 2 : 4)) void refine_stream_kernel(RefineArgs<TC, TQ> a, int64_t nq) {
     extern __shared__ __align__(16) unsigned char smem[];
-    refine_stream_run<TC, TQ, DC, GATHER>(a, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), nq, false);
+    refine_stream_run<TC, TQ, DC, GATHER, RefineNoFix, kMulti>(a, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), nq, false);
 }
 
 // Merge of per-chunk sorted top-k lists (B > kRefRows).  Each list is sorted by

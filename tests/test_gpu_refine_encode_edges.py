@@ -93,6 +93,33 @@ def test_refine_merge_of_many_partial_lists(pkg, oracle):
         _check_refine(pkg, oracle, q, cand, ids, cnt, k)
 
 
+@pytest.mark.parametrize("nq,B,k", [(3, 6000, 100), (1, 22000, 100), (40, 2048, 64), (700, 1024, 33), (5, 3000, 128), (2, 777, 40)])
+def test_refine_running_topk_over_runs_of_chunks(pkg, oracle, nq, B, k):
+    """Long lists, 32 < k <= 128: a workgroup walks a run of consecutive chunks of one query and keeps the best k in LDS
+    (refine_topk_running).  Few queries are cut into several runs (their lists merged by refine_merge_kernel), many queries get
+    one run each (no merge kernel).  Partial counts (trailing chunks empty or short), few distinct rows (ties across
+    chunks keep candidate order, QSI:298), NaN / Inf rows (skipped, QSI:407-413), counts below k — all vs the oracle."""
+    rng = np.random.default_rng(nq * 131 + B + k)
+    d = 16
+    q = rng.standard_normal((nq, d))
+    cand = rng.standard_normal((nq, B, d))
+    few = rng.standard_normal((nq, 12, d))
+    for i in range(0, nq, 2):                                   # every other query: only 12 distinct rows -> ties everywhere
+        cand[i] = few[i][rng.integers(0, 12, B)]
+    bad = rng.random((nq, B)) < 0.01
+    cand[bad, 3] = np.nan
+    cand[rng.random((nq, B)) < 0.005, 0] = np.inf
+    ids = rng.integers(0, 10**6, (nq, B)).astype(np.int32)
+    cnt = rng.integers(0, B + 1, nq).astype(np.int32)
+    cnt[0] = B
+    if nq > 1:
+        cnt[1] = k - 1                                          # fewer rows than k
+    if nq > 2:
+        cnt[2] = 257                                            # one full chunk and one row
+    for dt in (np.float32, np.float64):
+        _check_refine(pkg, oracle, q, cand, ids, cnt, k, dt)
+
+
 def test_refine_nonfinite(pkg, oracle):
     rng = np.random.default_rng(2)
     nq, B, d, k = 4, 256, 32, 10
