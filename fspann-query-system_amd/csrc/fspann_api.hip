@@ -58,6 +58,13 @@ template <typename T> void free_devt(T*& p) {
     p = nullptr;
 }
 
+constexpr size_t kPinBytes = size_t(1) << 20;
+// the context's pinned block (allocated at the first small host-pointer call; false: none, the general path runs)
+bool pin_block(fspann_ctx* c) {
+    if (!c->h_pin && hipHostMalloc(&c->h_pin, kPinBytes, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; (void)hipGetLastError(); }
+    return c->h_pin != nullptr;
+}
+
 int upload_index(fspann_ctx* c) {
     const int TD = c->TD, W = c->W;
     for (int td = 0; td < TD; td++)
@@ -763,6 +770,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     free_dev(c->ws_route.p); free_dev(c->ws_refine.p); free_dev(c->ws_probe.p); free_dev(c->ws_ovf.p); free_dev(c->ws_search.p); free_devt(c->d_inv); free_devt(c->d_ids_bk); free_devt(c->d_bin16);
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     if (parent) {
@@ -1362,6 +1370,47 @@ int fspann_route(fspann_ctx* c, int64_t nq, const uint64_t* codes, int probe_ove
     const size_t cb = static_cast<size_t>(nq) * c->TD * c->W * 8;
     const size_t ob = static_cast<size_t>(nq) * cap * 4;
     int rc;
+    // Small calls (QueryService.search is one token per call, ForwardSecureANNSystem.java:636): codes go up and lists, scores and
+    // counts come down through ONE pinned block — one asynchronous copy each way and one synchronisation, where the general path
+    // below pays a synchronous pageable copy per argument and a separate look at the counts (bench.py operator_surface).
+    const size_t ob_a = (ob + 15) & ~size_t(15), cnt_a = (static_cast<size_t>(nq) * 12 + 15) & ~size_t(15);
+    if (std::max(cb, 2 * ob_a + cnt_a) <= kPinBytes && pin_block(c)) {
+        unsigned char* hp = static_cast<unsigned char*>(c->h_pin);
+        if ((rc = ensure(c, c->ws_io[0], cb))) return rc;
+        if ((rc = ensure(c, c->ws_io[1], 2 * ob_a + cnt_a))) return rc;       // ids | scores | count, kept, rawSeen: one block
+        unsigned char* dv = static_cast<unsigned char*>(c->ws_io[1].p);
+        int32_t* ids_d = reinterpret_cast<int32_t*>(dv), *sc_d = reinterpret_cast<int32_t*>(dv + ob_a), *cnt_d = reinterpret_cast<int32_t*>(dv + 2 * ob_a);
+        std::memcpy(hp, codes, cb);
+        FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, hp, cb, hipMemcpyHostToDevice, c->stream));
+        rc = fspann_route_dev(c, nq, static_cast<const uint64_t*>(c->ws_io[0].p), probe_override, limit, cap, ids_d, sc_d, cnt_d,
+                              kept ? cnt_d + nq : nullptr, raw_seen ? cnt_d + 2 * nq : nullptr);
+        if (rc) return rc;
+        for (int pass = 0; pass < 2; pass++) {
+            FSP_HIP(hipMemcpyAsync(hp, dv, 2 * ob_a + cnt_a, hipMemcpyDeviceToHost, c->stream));
+            FSP_HIP(hipStreamSynchronize(c->stream));
+            const int32_t* cnt_h = reinterpret_cast<const int32_t*>(hp + 2 * ob_a);
+            bool flagged = false;
+            for (int64_t i = 0; i < nq; i++) flagged = flagged || cnt_h[i] < 0;
+            if (!flagged || pass == 1) break;
+            // (rare) a bestScore map treeified a bin: finished by the literal JDK model on the host, then fetched again
+            rc = guarded([&]() -> int {
+                return resolve_unmodelled(c, nq, static_cast<const uint64_t*>(c->ws_io[0].p), probe_override, limit, cap, ids_d, sc_d, cnt_d,
+                                          kept ? cnt_d + nq : nullptr, raw_seen ? cnt_d + 2 * nq : nullptr, nullptr, nullptr);
+            });
+            if (rc) return rc;
+        }
+        const int32_t* cnt_h = reinterpret_cast<const int32_t*>(hp + 2 * ob_a);
+        std::memcpy(ids, hp, ob);
+        if (score) std::memcpy(score, hp + ob_a, ob);
+        std::memcpy(count, cnt_h, static_cast<size_t>(nq) * 4);
+        if (kept) std::memcpy(kept, cnt_h + nq, static_cast<size_t>(nq) * 4);
+        if (raw_seen) std::memcpy(raw_seen, cnt_h + 2 * nq, static_cast<size_t>(nq) * 4);
+        for (int64_t i = 0; i < nq; i++)
+            if (count[i] < 0)
+                return fail(FSPANN_E_STATE, "query %lld: a treeified HashMap bin of bestScore orders different ids with equal String.hashCode by "
+                            "String.compareTo, which the library cannot evaluate for non-decimal ids: not modelled, its count is -1", (long long)i);
+        return FSPANN_OK;
+    }
     if ((rc = ensure(c, c->ws_io[0], cb))) return rc;
     if ((rc = ensure(c, c->ws_io[1], ob))) return rc;
     if ((rc = ensure(c, c->ws_io[2], ob))) return rc;
@@ -1430,6 +1479,36 @@ int fspann_refine(fspann_ctx* c, int64_t nq, const void* q, const void* cand, in
     const size_t ib = static_cast<size_t>(nq) * B * 4, nb = static_cast<size_t>(nq) * 4;
     const size_t ob_i = static_cast<size_t>(nq) * k * 4, ob_d = static_cast<size_t>(nq) * k * 8;
     int rc;
+    // Small calls: query, ids and counts go up in ONE pinned block and every output comes down in one (the candidate rows keep
+    // their own copy straight from the caller's buffer): three transfers and one synchronisation instead of eight and one.
+    {
+        auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+        const size_t up = al(qb) + al(ib) + al(nb), down = al(ob_d) + al(ob_i) + al(2 * nb);
+        if (std::max(up, down) <= kPinBytes && pin_block(c)) {
+            unsigned char* hp = static_cast<unsigned char*>(c->h_pin);
+            if ((rc = ensure(c, c->ws_io[0], up))) return rc;
+            if ((rc = ensure(c, c->ws_io[1], cb))) return rc;
+            if ((rc = ensure(c, c->ws_io[4], down))) return rc;
+            unsigned char* du = static_cast<unsigned char*>(c->ws_io[0].p), *dd = static_cast<unsigned char*>(c->ws_io[4].p);
+            std::memcpy(hp, q, qb);
+            std::memcpy(hp + al(qb), cand_ids, ib);
+            std::memcpy(hp + al(qb) + al(ib), cand_count, nb);
+            FSP_HIP(hipMemcpyAsync(du, hp, up, hipMemcpyHostToDevice, c->stream));
+            FSP_HIP(hipMemcpyAsync(c->ws_io[1].p, cand, cb, hipMemcpyHostToDevice, c->stream));
+            int32_t* cnt_out = reinterpret_cast<int32_t*>(dd + al(ob_d) + al(ob_i));
+            rc = fspann_refine_dev(c, nq, du, dtype, c->ws_io[1].p, dtype, B, reinterpret_cast<int32_t*>(du + al(qb)),
+                                   reinterpret_cast<int32_t*>(du + al(qb) + al(ib)), k, reinterpret_cast<int32_t*>(dd + al(ob_d)),
+                                   reinterpret_cast<double*>(dd), cnt_out, cnt_out + nq);
+            if (rc) return rc;
+            FSP_HIP(hipMemcpyAsync(hp, dd, down, hipMemcpyDeviceToHost, c->stream));   // (stream order: the way up has been read by then)
+            FSP_HIP(hipStreamSynchronize(c->stream));
+            std::memcpy(out_dist, hp, ob_d);
+            std::memcpy(out_ids, hp + al(ob_d), ob_i);
+            std::memcpy(out_count, hp + al(ob_d) + al(ob_i), nb);
+            if (scored) std::memcpy(scored, hp + al(ob_d) + al(ob_i) + nb, nb);
+            return FSPANN_OK;
+        }
+    }
     if ((rc = ensure(c, c->ws_io[0], qb))) return rc;
     if ((rc = ensure(c, c->ws_io[1], cb))) return rc;
     if ((rc = ensure(c, c->ws_io[2], ib))) return rc;

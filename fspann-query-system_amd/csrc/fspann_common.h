@@ -181,6 +181,8 @@ struct fspann_ctx {
     unsigned fix_valid = 0;
     int fix_next = 0;
     fspann::DevBuf ws_io[8];   // staging for the host-pointer entry points
+    void* h_pin = nullptr;     // pinned host block (kPinBytes) for the small transfers of the host-pointer entry points: one H2D and one D2H
+                               //   per call instead of one synchronous pageable copy per argument (a per-query caller pays each of them)
     // transient, set by fspann_tick_dev around a refine-only tick: device-resident RouteParams of the batch's hand-over buffer
     // (the streaming scan then finishes PENDING queries itself), the LDS its full select needs, and whether a launch took it
     const void* refine_fix_dev = nullptr;

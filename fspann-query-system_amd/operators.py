@@ -364,6 +364,15 @@ class PartitionedIndexService:
         ids = [self._ids[h] for h in res["ids"][0, :n]]
         return ids, res["score"][0, :n], int(res["kept"][0])
 
+    def _route_batch(self, codes_list, limit, probe_override):
+        """One fspann_route for a batch of tokens: per token (ids, scores, kept, rawSeen)."""
+        res = self.ctx.route(np.stack(codes_list), probe_override=probe_override, limit=limit)
+        out = []
+        for i in range(len(codes_list)):
+            n = int(res["count"][i])
+            out.append(([self._ids[h] for h in res["ids"][i, :n]], res["score"][i, :n], int(res["kept"][i]), int(res["raw_seen"][i])))
+        return out
+
     def lookupCandidatesWithScores(self, token) -> List[CandidateWithScore]:  # PIS:592-715
         codes = self._checkToken(token)
         if codes is None:
@@ -553,7 +562,96 @@ class QueryServiceImpl:
                 self.reencTracker.record(set(self.touchedThisSession))
 
     def _search_many(self, tokens):
-        return [self._search_one(t) for t in tokens]
+        """The batched mirror (GpuQueryServiceImpl.searchBatch): the reference calls search(token) once per query from one serial
+        loop (ForwardSecureANNSystem.java:636-748); here the tokens of a batch share ONE fspann_route, the host decrypt loop
+        (QSI:238-271, unchanged) runs over every F_q, and ONE fspann_refine scores all of them — then the adaptive retry
+        (QSI:327-337) reruns, again as one batch, exactly the queries that came back short.  Results per token are those of
+        search(token); the metric getters describe the LAST token, `touchedThisSession` is per token as in the reference."""
+        idx = self.index
+        n = len(tokens)
+        results: List[List[QueryResult]] = [[] for _ in range(n)]
+        Ks = {t.getTopK() for t in tokens if t is not None}
+        if len(Ks) != 1:                          # mixed topK: fspann_refine takes one k per call
+            return [self._search_one(t) for t in tokens]
+        K = Ks.pop()
+        qvecs, codes = {}, {}
+        for i, t in enumerate(tokens):            # QSI:102-140 per token
+            if t is None:
+                continue
+            try:
+                qkv = self.keyService.getVersion(t.getVersion())
+            except Exception:
+                qkv = self.keyService.getCurrentVersion()
+            qv = np.asarray(self.cryptoService.decryptQuery(t.getEncryptedQuery(), t.getIv(), qkv.key), np.float64)
+            if not np.all(np.isfinite(qv)):
+                continue
+            c = idx._checkToken(t)
+            if c is None:
+                continue
+            qvecs[i], codes[i] = qv, c
+        metrics = {i: dict(total=0, kept=0, decrypted=0, returned=0, unique=0, ids=[], touched=set()) for i in range(n)}
+        active = sorted(qvecs)
+        probe = idx._probeOverride
+        limit = self.getEffectiveRefinementLimit(self.cfg.refinementLimit)
+        try:
+            for attempt in range(2):
+                if not active:
+                    break
+                routed = idx._route_batch([codes[i] for i in active], limit, probe)            # stage A + A.5: one call
+                rows_all, rids_all = {}, {}
+                for i, (ids, _score, kept, raw) in zip(active, routed):
+                    m = metrics[i]
+                    m["total"], m["kept"], m["unique"] = raw, kept, len(ids)
+                    rows, rids = [], []
+                    for cid in ids:                                                           # stage B host part (QSI:238-271)
+                        try:
+                            ep = idx.loadPointIfActive(cid)
+                            if ep is None:
+                                continue
+                            v = np.asarray(self.cryptoService.decryptFromPoint(ep, self.keyService.getVersion(ep.version).key), np.float64)
+                            if v.shape != qvecs[i].shape or not np.all(np.isfinite(v)):
+                                continue
+                            rows.append(v)
+                            rids.append(cid)
+                            m["touched"].add(cid)
+                        except Exception:
+                            continue
+                    m["decrypted"] = len(rows)
+                    rows_all[i], rids_all[i] = rows, rids
+                    if not rows:
+                        results[i], m["returned"], m["ids"] = [], 0, []
+                scored = [i for i in active if rows_all[i]]
+                if scored:
+                    Bm = max(len(rows_all[i]) for i in scored)
+                    dim = len(qvecs[scored[0]])
+                    cand = np.zeros((len(scored), Bm, dim), np.float64)
+                    cnt = np.zeros(len(scored), np.int32)
+                    for j, i in enumerate(scored):
+                        cand[j, :len(rows_all[i])] = np.stack(rows_all[i])
+                        cnt[j] = len(rows_all[i])
+                    res = idx.ctx.refine(np.stack([qvecs[i] for i in scored]), cand, np.tile(np.arange(Bm, dtype=np.int32), (len(scored), 1)),
+                                         cnt, K)                                              # stage B distances + C: one call
+                    for j, i in enumerate(scored):
+                        eff = int(res["count"][j])
+                        out = [QueryResult(rids_all[i][r], float(dd)) for r, dd in zip(res["ids"][j, :eff], res["dist"][j, :eff])]
+                        results[i] = out
+                        metrics[i]["returned"], metrics[i]["ids"] = eff, [r.id for r in out]
+                if attempt == 0:                   # QSI:327-337,444-447: one more pass with 10 probes for the short ones
+                    active = [i for i in active if rows_all[i] and (metrics[i]["returned"] < K or metrics[i]["decrypted"] < 10 * K)]
+                    probe = 10
+        finally:
+            idx.clearProbeOverride()
+        self._clear()
+        last = max(metrics) if metrics else None
+        for i in range(n):
+            if self.reencTracker is not None and metrics[i]["touched"]:
+                self.reencTracker.record(set(metrics[i]["touched"]))
+        if last is not None:
+            m = metrics[last]
+            self.lastCandTotal, self.lastCandKept, self.lastCandDecrypted = m["total"], m["kept"], m["decrypted"]
+            self.lastReturned, self.lastCandIds, self.lastUniqueCandidates = m["returned"], m["ids"], m["unique"]
+            self.touchedThisSession = set(m["touched"])
+        return results
 
     # metrics / overrides (QSI:417-474)
     def getLastCandTotal(self): return self.lastCandTotal

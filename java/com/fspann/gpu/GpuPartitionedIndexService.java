@@ -211,6 +211,53 @@ public final class GpuPartitionedIndexService implements IndexService, AutoClose
         return out;
     }
 
+    /**
+     * Stage A + A.5 for a BATCH of tokens with ONE fspann_route (GpuQueryServiceImpl.searchBatch): entry q of the result is what
+     * route(tokens.get(q), limit, ...) returns; a token of another dimension yields an empty list (PIS:598).  keptOut / rawOut
+     * (length = tokens.size(), may be null) receive lastCandKept / rawSeen per token when withCounters is set.  probes: the probe
+     * override of this pass (-1 = default; the caller's adaptive retry passes 10).
+     */
+    List<List<CandidateWithScore>> routeBatch(List<QueryToken> tokens, int limit, int probes, boolean withCounters, int[] keptOut, int[] rawOut) {
+        final int nq = tokens.size();
+        List<List<CandidateWithScore>> out = new ArrayList<>(nq);
+        final long codeBytes = 8L * tables * divisions * words;
+        ByteBuffer codes = buf(codeBytes * nq);
+        int[] slot = new int[nq];
+        int live = 0;
+        for (int q = 0; q < nq; q++) {
+            out.add(new ArrayList<>());
+            ByteBuffer c = tokenCodes(tokens.get(q));
+            slot[q] = -1;
+            if (c == null) continue;
+            c.flip();
+            codes.put(c);
+            slot[q] = live++;
+        }
+        if (live == 0) return out;
+        long cap = Math.max(1, Math.min((long) limit, FspannNative.routeMaxCandidates(ctx, probes)));
+        ByteBuffer ids = buf(4 * cap * live), sc = buf(4 * cap * live), cnt = buf(4L * live);
+        ByteBuffer kept = withCounters ? buf(4L * live) : null, raw = withCounters ? buf(4L * live) : null;
+        FspannNative.check(FspannNative.route(ctx, live, codes, probes, limit, cap, ids, sc, cnt, kept, raw));
+        Set<String> touched = lastTouched.get();
+        touched.clear();
+        for (int q = 0; q < nq; q++) {
+            if (slot[q] < 0) continue;
+            final int s = slot[q], n = cnt.getInt(4 * s);
+            List<CandidateWithScore> lq = out.get(q);
+            for (int i = 0; i < n; i++) {
+                String id = idOf.get(ids.getInt((int) (4 * (s * cap + i))));
+                lq.add(new CandidateWithScore(id, sc.getInt((int) (4 * (s * cap + i)))));
+                if (q == nq - 1) touched.add(id);                                   // getLastTouchedIds describes the last token
+            }
+            if (withCounters) {
+                if (keptOut != null) keptOut[q] = kept.getInt(4 * s);
+                if (rawOut != null) rawOut[q] = raw.getInt(4 * s);
+                if (q == nq - 1) lastRawVisited = raw.getInt(4 * s);
+            }
+        }
+        return out;
+    }
+
     public List<CandidateWithScore> lookupCandidatesWithScores(QueryToken token) {
         return route(token, Integer.MAX_VALUE, true, null);
     }

@@ -141,6 +141,123 @@ public final class GpuQueryServiceImpl implements QueryService {
         }
     }
 
+    /**
+     * The batched mirror of search(): the reference's runQueries loop calls search(token) once per query
+     * (ForwardSecureANNSystem.java:636-748), which costs a GPU round trip per query per stage (bench.py operator_surface.per_query).
+     * Here the tokens of a batch share ONE fspann_route, the host load + decrypt loop (QSI:238-271, unchanged) runs over every
+     * F_q into one direct buffer, ONE fspann_refine scores all of them, and the adaptive retry (QSI:327-337) reruns — again as
+     * one batch — exactly the queries that came back short.  Entry q is what search(tokens.get(q)) returns; the metric getters
+     * describe the last token; the re-encryption tracker records every token's touched ids.  All tokens must ask for the same
+     * topK (fspann_refine takes one k per call); otherwise the tokens are searched one by one.
+     * Python twin: operators.QueryServiceImpl.searchBatch (tests/test_gpu_golden.py).
+     */
+    public List<List<QueryResult>> searchBatch(List<QueryToken> tokens) {
+        final int nq = tokens.size();
+        List<List<QueryResult>> results = new ArrayList<>(nq);
+        for (int i = 0; i < nq; i++) results.add(Collections.emptyList());
+        int K = -1;
+        boolean sameK = true;
+        for (QueryToken t : tokens) if (t != null) { if (K < 0) K = t.getTopK(); else sameK &= (K == t.getTopK()); }
+        if (K < 0) return results;
+        if (!sameK) { for (int i = 0; i < nq; i++) results.set(i, search(tokens.get(i))); return results; }
+        final long t0 = System.nanoTime();
+        long decryptNs = 0;
+        double[][] qv = new double[nq][];
+        List<Integer> active = new ArrayList<>();
+        for (int i = 0; i < nq; i++) {                                            // QSI:102-140 per token
+            QueryToken token = tokens.get(i);
+            if (token == null) continue;
+            try {
+                KeyVersion kv;
+                try { kv = keyService.getVersion(token.getVersion()); } catch (RuntimeException e) { kv = keyService.getCurrentVersion(); }
+                double[] q = cryptoService.decryptQuery(token.getEncryptedQuery(), token.getIv(), kv.getKey());
+                if (isValid(q)) { qv[i] = q; active.add(i); }
+            } catch (RuntimeException e) { /* empty result */ }
+        }
+        final int limit = getEffectiveRefinementLimit(cfg.getRuntime().getRefinementLimit());
+        lastEffectiveLimit = limit;
+        final boolean counters = index.countersWanted();
+        int[] kept = new int[nq], raw = new int[nq], decrypted = new int[nq], returned = new int[nq], unique = new int[nq];
+        List<Set<String>> touched = new ArrayList<>(nq);
+        for (int i = 0; i < nq; i++) touched.add(new HashSet<>());
+        List<String> finLast = Collections.emptyList();
+        try {
+            int probes = -1;
+            for (int attempt = 0; attempt < 2 && !active.isEmpty(); attempt++) {
+                List<QueryToken> toks = new ArrayList<>(active.size());
+                for (int i : active) toks.add(tokens.get(i));
+                int[] keptA = new int[active.size()], rawA = new int[active.size()];
+                List<List<GpuPartitionedIndexService.CandidateWithScore>> fqs = index.routeBatch(toks, limit, probes, counters, keptA, rawA);   // stage A + A.5: one call
+                // stage B, host part — the reference's loop (QSI:238-271) over every F_q; rows packed as [query][Bmax][dim]
+                final long td0 = System.nanoTime();
+                int bmax = 0;
+                for (List<GpuPartitionedIndexService.CandidateWithScore> fq : fqs) bmax = Math.max(bmax, fq.size());
+                if (bmax == 0) break;
+                final int dim = qv[active.get(0)].length, na = active.size();
+                ByteBuffer rows = buf(8L * na * bmax * dim), ids = buf(4L * na * bmax), cnt = buf(4L * na), qb = buf(8L * na * dim);
+                List<List<String>> rowIds = new ArrayList<>(na);
+                for (int a = 0; a < na; a++) {
+                    final int i = active.get(a);
+                    kept[i] = counters ? keptA[a] : -1; raw[i] = counters ? rawA[a] : -1; unique[i] = fqs.get(a).size();
+                    List<String> rid = new ArrayList<>(fqs.get(a).size());
+                    int pos = (int) (8L * a * bmax * dim);
+                    for (GpuPartitionedIndexService.CandidateWithScore c : fqs.get(a)) {
+                        try {
+                            EncryptedPoint ep = index.loadPointIfActive(c.id());
+                            if (ep == null) continue;
+                            double[] v = cryptoService.decryptFromPoint(ep, keyService.getVersion(ep.getKeyVersion()).getKey());
+                            if (!isValid(v) || v.length != dim) continue;
+                            for (double x : v) { rows.putDouble(pos, x); pos += 8; }
+                            ids.putInt(4 * (a * bmax + rid.size()), rid.size());
+                            rid.add(c.id());
+                            touched.get(i).add(c.id());
+                        } catch (Exception e) { /* per-candidate failures are swallowed (QSI:264-269) */ }
+                    }
+                    rowIds.add(rid);
+                    decrypted[i] = rid.size();
+                    cnt.putInt(4 * a, rid.size());
+                    for (int j = 0; j < dim; j++) qb.putDouble(8 * (a * dim + j), qv[i][j]);
+                    if (rid.isEmpty()) { results.set(i, Collections.emptyList()); returned[i] = 0; }
+                }
+                decryptNs += System.nanoTime() - td0;
+                // stage B distances + stage C: one call for the batch (a query without rows has count 0 and gets an empty result)
+                ByteBuffer oi = buf(4L * na * K), od = buf(8L * na * K), oc = buf(4L * na), sc = buf(4L * na);
+                FspannNative.check(FspannNative.refine(index.nativeContext(), na, qb, rows, FspannNative.F64, bmax, ids, cnt, K, oi, od, oc, sc));
+                List<Integer> again = new ArrayList<>();
+                for (int a = 0; a < na; a++) {
+                    final int i = active.get(a);
+                    if (rowIds.get(a).isEmpty()) continue;
+                    int eff = oc.getInt(4 * a);
+                    List<QueryResult> out = new ArrayList<>(eff);
+                    List<String> fin = new ArrayList<>(eff);
+                    for (int r = 0; r < eff; r++) {
+                        String id = rowIds.get(a).get(oi.getInt(4 * (a * K + r)));
+                        out.add(new QueryResult(id, od.getDouble(8 * (a * K + r))));
+                        fin.add(id);
+                    }
+                    results.set(i, out);
+                    returned[i] = eff;
+                    if (i == nq - 1) finLast = fin;
+                    if (attempt == 0 && (eff < K || decrypted[i] < 10 * K)) again.add(i);      // QSI:327-337,444-447
+                }
+                active = again;
+                probes = 10;
+            }
+        } finally {                                                              // QSI:342-351
+            index.clearProbeOverride();
+            lastServerNs = System.nanoTime() - t0;
+            lastDecryptNs = decryptNs;
+            lastClientNs = 0;
+            final int l = nq - 1;
+            lastCandTotal = raw[l]; lastCandKept = kept[l]; lastCandDecrypted = decrypted[l]; lastReturned = returned[l];
+            lastUniqueCandidates = unique[l]; lastFinalIds = finLast;
+            touchedThisSession.clear();
+            touchedThisSession.addAll(touched.get(l));
+            if (reencTracker != null) for (Set<String> ts : touched) if (!ts.isEmpty()) reencTracker.record(new HashSet<>(ts));
+        }
+        return results;
+    }
+
     // ---- accessors of QueryServiceImpl (QSI:83-87,417-474) ----------------------------------------------------------------
     public void setReencryptionTracker(ReencryptionTracker tr) { this.reencTracker = tr; }
     public List<String> getLastFinalResultIds() { return lastFinalIds; }

@@ -83,6 +83,19 @@ def test_operator_mirror_matches_golden(pkg, name):
             mt = g["search_metrics"][qi]
             assert (qs.getLastCandTotal(), qs.getLastCandKept(), qs.getLastCandDecrypted(), qs.getLastReturned()) == \
                 tuple(int(x) for x in mt[:4])
+        # the batched mirror (GpuQueryServiceImpl.searchBatch): ONE fspann_route + ONE fspann_refine for all tokens, the adaptive
+        # retry (QSI:327-337) as a second batch of exactly the short queries — per token the same lists, bit for bit; the metric
+        # getters describe the last token
+        toks = tf.createBatch(list(g["Q"]), K)
+        many = qs.searchBatch(toks)
+        assert len(many) == len(g["Q"]) > 1
+        for qi, res in enumerate(many):
+            cnt = int(g["search_count"][qi])
+            assert [int(r.id) for r in res] == list(g["search_ids"][qi, :cnt]), qi
+            assert [r.distance for r in res] == list(g["search_dist"][qi, :cnt]), qi
+        mt = g["search_metrics"][len(g["Q"]) - 1]
+        assert (qs.getLastCandTotal(), qs.getLastCandKept(), qs.getLastCandDecrypted(), qs.getLastReturned()) == tuple(int(x) for x in mt[:4])
+        assert qs.searchBatch([None, toks[0]])[0] == [] and [int(r.id) for r in qs.searchBatch([None, toks[0]])[1]] == list(g["search_ids"][0, :int(g["search_count"][0])])
     finally:
         if index.ctx is not None:
             index.ctx.close()

@@ -3,6 +3,7 @@ import ctypes as C, sys, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
+if os.environ.get('AB_LIB'): pkg._native._SO = os.path.abspath(os.environ['AB_LIB'])
 n, d, T, D, m, lam, B, Q = 1_000_000, 128, 16, 1, 16, 2, 256, 1024
 rng = np.random.default_rng(1)
 X = rng.standard_normal((n, d), dtype=np.float32)
