@@ -883,6 +883,33 @@ def main():
                                "H2D + Refine (GPU), four batches in flight; record format, AAD and key derivation are the reference's "
                                "(AesGcmCryptoService.java:55-166, EncryptedPoint.java:80-83, KeyManager.java:221-237); host-bound by design")
 
+    # ... and what ONE host thread pays per open against the bare cipher (tools/micro/open_bench.cpp: the store's own header built
+    # with g++ on this box; a report, skipped when there is no compiler)
+    if end_to_end is not None:
+        try:
+            import re
+            import subprocess
+            import tempfile
+            exe = os.path.join(tempfile.gettempdir(), "fspann_open_bench_%d" % os.getpid())
+            subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tools", "micro", "open_bench.cpp"), "-ldl", "-o", exe],
+                           check=True, capture_output=True, timeout=120)
+            ob = subprocess.run([exe, str(Q * B), str(end_to_end["host_threads"])], check=True, capture_output=True, text=True, timeout=120).stdout
+            os.unlink(exe)
+            bare = float(re.search(r"hot: ([0-9.]+) us per message", ob).group(1))
+            one = float(re.search(r"pointstore_open_one, 1 thread, scattered: ([0-9.]+) us", ob).group(1))
+            many = [float(x) for x in re.findall(r"pointstore_open_batch<float>, \d+ threads: ([0-9.]+) ms", ob)]
+            end_to_end["per_open"] = dict(
+                bare_cipher_us=bare, open_one_thread_us=one, ratio_to_bare_cipher=round(one / bare, 2),
+                opens_per_s_per_core=round(1e6 / one, 1),
+                batch_ms=min(many) if many else None,
+                cores_worth_of_the_thread_pool=round((Q * B / (min(many) * 1e-3)) / (1e6 / one), 2) if many else None,
+                parts_us={k_: float(v_) for k_, v_ in re.findall(r"^  (.+?)\s{2,}([0-9.]+) us", ob, flags=re.M)},
+                note="one thread: EVP AES-256-GCM over one hot 1 040-byte record (bare cipher) vs pointstore_open_one over scattered records "
+                     "(version check, snapshot, AAD, cipher, tag, big-endian fp64 decode); the thread pool's rate over the one-thread rate = how "
+                     "many cores' worth of CPU the box gives this process")
+        except Exception as e:
+            end_to_end["per_open"] = dict(error=str(e)[:200])
+
     # one more (untimed) step of batch 0 on context 0: its results are what recall and the CPU baseline are checked on
     flagged_in_timed_runs = sum(int(c_.unmodelled_queries()) for c_ in ctxs)     # (read + reset: the timed steps leave such queries empty)
     for b_ in bufs:

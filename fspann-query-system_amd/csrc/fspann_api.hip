@@ -2048,7 +2048,7 @@ int fspann_pointstore_create(int64_t n, int dim, fspann_pointstore** out) {
         fspann_pointstore* ps = new fspann_pointstore();
         ps->n = n;
         ps->dim = dim;
-        ps->stride = (4 + kIvBytes + 8 * static_cast<size_t>(dim) + kTagBytes + 7) & ~size_t(7);
+        ps->stride = pointstore_stride(dim);
         ps->mem.assign(static_cast<size_t>(n) * ps->stride, 0);
         *out = ps;
         return FSPANN_OK;
@@ -2141,8 +2141,8 @@ int fspann_pointstore_get_record(fspann_pointstore* ps, int64_t h, int32_t* vers
     if (h < 0 || h >= ps->n) return fail(FSPANN_E_ARG, "handle out of range");
     const int v = ps->ver(h)->load(std::memory_order_acquire);
     if (version) *version = v;
-    if (iv12) copy_from_shared(iv12, ps->rec(h) + 4, kIvBytes);
-    if (ct) copy_from_shared(ct, ps->rec(h) + 4 + kIvBytes, 8 * static_cast<size_t>(ps->dim) + kTagBytes);
+    if (iv12) copy_from_shared(iv12, ps->rec(h) + kRecHeader, kIvBytes);
+    if (ct) copy_from_shared(ct, ps->rec(h) + kRecHeader + kIvBytes, 8 * static_cast<size_t>(ps->dim) + kTagBytes);
     return FSPANN_OK;
 }
 // Import a record sealed elsewhere (the JVM's EncryptedPoint: keyVersion, iv, ciphertext || tag).
@@ -2151,8 +2151,8 @@ int fspann_pointstore_put_record(fspann_pointstore* ps, int64_t h, int32_t versi
     if (h < 0 || h >= ps->n) return fail(FSPANN_E_ARG, "handle out of range");
     if (version <= 0) return fail(FSPANN_E_ARG, "version <= 0");
     (void)acquire_record(ps, h);
-    copy_to_shared(ps->rec(h) + 4, iv12, kIvBytes);
-    copy_to_shared(ps->rec(h) + 4 + kIvBytes, ct, 8 * static_cast<size_t>(ps->dim) + kTagBytes);
+    copy_to_shared(ps->rec(h) + kRecHeader, iv12, kIvBytes);
+    copy_to_shared(ps->rec(h) + kRecHeader + kIvBytes, ct, 8 * static_cast<size_t>(ps->dim) + kTagBytes);
     ps->ver(h)->store(version, std::memory_order_release);
     return FSPANN_OK;
 }

@@ -80,22 +80,36 @@ inline CryptoApi* crypto_api() {
 
 constexpr int kGcmSetIvLen = 0x9, kGcmGetTag = 0x10, kGcmSetTag = 0x11;   // EVP_CTRL_AEAD_*
 constexpr int kIvBytes = 12, kTagBytes = 16;
+constexpr int kRecHeader = 8;        // bytes in front of a record's payload (iv || ciphertext || tag): the version word + 4 of padding, so the
+                                     //   payload starts on an 8-byte boundary and is snapshotted in 8-byte words
+inline size_t pointstore_stride(int dim) { return (kRecHeader + kIvBytes + 8 * static_cast<size_t>(dim) + kTagBytes + 7) & ~size_t(7); }
 
 inline uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
 
 // The bytes of a record are read by query threads while a Migrate may be rewriting them; the per-record version word decides
 // afterwards whether a snapshot is usable (seqlock).  The copies themselves therefore go through relaxed ATOMIC word accesses:
 // a torn snapshot is expected and discarded, a data race in the C++ sense it is not (and ThreadSanitizer agrees).
-// `shared` is 4-byte aligned (records start on 8-byte strides, payload at +4), n a multiple of 4.
+// `shared` is at least 4-byte aligned (records start on 8-byte strides, payload at +kRecHeader), n a multiple of 4; 8-byte words
+// where the address allows.
 inline void copy_from_shared(void* dst, const void* shared, size_t n) {
-    const uint32_t* s = static_cast<const uint32_t*>(shared);
     unsigned char* d = static_cast<unsigned char*>(dst);
-    for (size_t i = 0; i < n / 4; i++) { const uint32_t v = __atomic_load_n(s + i, __ATOMIC_RELAXED); std::memcpy(d + 4 * i, &v, 4); }
+    size_t i = 0;
+    if ((reinterpret_cast<uintptr_t>(shared) & 7) == 0) {
+        const uint64_t* s8 = static_cast<const uint64_t*>(shared);
+        for (; i + 8 <= n; i += 8) { const uint64_t v = __atomic_load_n(s8 + i / 8, __ATOMIC_RELAXED); std::memcpy(d + i, &v, 8); }
+    }
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(shared) + i);
+    for (size_t k = 0; i + 4 <= n; i += 4, k++) { const uint32_t v = __atomic_load_n(s + k, __ATOMIC_RELAXED); std::memcpy(d + i, &v, 4); }
 }
 inline void copy_to_shared(void* shared, const void* src, size_t n) {
-    uint32_t* d = static_cast<uint32_t*>(shared);
     const unsigned char* s = static_cast<const unsigned char*>(src);
-    for (size_t i = 0; i < n / 4; i++) { uint32_t v; std::memcpy(&v, s + 4 * i, 4); __atomic_store_n(d + i, v, __ATOMIC_RELAXED); }
+    size_t i = 0;
+    if ((reinterpret_cast<uintptr_t>(shared) & 7) == 0) {
+        uint64_t* d8 = static_cast<uint64_t*>(shared);
+        for (; i + 8 <= n; i += 8) { uint64_t v; std::memcpy(&v, s + i, 8); __atomic_store_n(d8 + i / 8, v, __ATOMIC_RELAXED); }
+    }
+    uint32_t* d = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(shared) + i);
+    for (size_t k = 0; i + 4 <= n; i += 4, k++) { uint32_t v; std::memcpy(&v, s + i, 4); __atomic_store_n(d + k, v, __ATOMIC_RELAXED); }
 }
 
 // One pair of reusable cipher contexts per worker thread (the reference pays Cipher.getInstance per candidate).  The cipher is
@@ -210,8 +224,29 @@ inline int32_t acquire_record(fspann_pointstore* ps, int64_t h) {
     }
 }
 
-inline int aad_for(char* buf, size_t cap, int64_t handle, int version, int dim) {   // EncryptedPoint.java:80-83, id = Long.toString(handle)
-    return snprintf(buf, cap, "id:%lld|v:%d|d:%d", static_cast<long long>(handle), version, dim);
+// "id:%s|v:%d|d:%d" (EncryptedPoint.java:80-83, id = Long.toString(handle)) without snprintf: it is built once per record on the
+// open path (tools/micro/open_bench.cpp: 0.10 us of a 0.38 us cipher call through snprintf)
+inline int put_dec(char* p, long long v) {
+    char tmp[24];
+    int n = 0;
+    unsigned long long u = v < 0 ? 0ull - static_cast<unsigned long long>(v) : static_cast<unsigned long long>(v);
+    do { tmp[n++] = static_cast<char>('0' + u % 10); u /= 10; } while (u);
+    int k = 0;
+    if (v < 0) p[k++] = '-';
+    while (n) p[k++] = tmp[--n];
+    return k;
+}
+inline int aad_for(char* buf, size_t cap, int64_t handle, int version, int dim) {
+    if (cap < 80) return snprintf(buf, cap, "id:%lld|v:%d|d:%d", static_cast<long long>(handle), version, dim);
+    int k = 0;
+    buf[k++] = 'i'; buf[k++] = 'd'; buf[k++] = ':';
+    k += put_dec(buf + k, handle);
+    buf[k++] = '|'; buf[k++] = 'v'; buf[k++] = ':';
+    k += put_dec(buf + k, version);
+    buf[k++] = '|'; buf[k++] = 'd'; buf[k++] = ':';
+    k += put_dec(buf + k, dim);
+    buf[k] = 0;
+    return k;
 }
 
 // Run fn(worker_index, begin, end) over [0, n) on `threads` threads (contiguous ranges handed out in blocks of `grain`).
@@ -268,15 +303,75 @@ inline int pointstore_encrypt(fspann_pointstore* ps, int64_t h0, int64_t cnt, co
             std::memcpy(sealed.data(), iv, kIvBytes);
             if (!w.seal(iv, reinterpret_cast<const unsigned char*>(aad), al, pt.data(), ptlen, sealed.data() + kIvBytes)) { (*bad)++; continue; }
             (void)acquire_record(ps, h);                               // being written: -1 is visible before the record's bytes change
-            copy_to_shared(r + 4, sealed.data(), sealed.size());
+            copy_to_shared(r + kRecHeader, sealed.data(), sealed.size());
             ps->ver(h)->store(v, std::memory_order_release);
         }
     });
     return 0;
 }
 
+// deserializeVector (AesGcmCryptoService.java:261-277): dim big-endian IEEE-754 doubles -> host doubles / the fp32 staging type
+inline void decode_row(const unsigned char* pt, int dim, double* out) {
+    for (int j = 0; j < dim; j++) {
+        uint64_t bits;
+        std::memcpy(&bits, pt + 8 * j, 8);
+        bits = bswap64(bits);
+        std::memcpy(out + j, &bits, 8);
+    }
+}
+inline void decode_row(const unsigned char* pt, int dim, float* out) {       // (double) -> float: the narrowing QSI never does — exact for
+    for (int j = 0; j < dim; j++) {                                           //   fvecs-derived data, the fp32-staged block of SURVEY §8d)
+        uint64_t bits;
+        std::memcpy(&bits, pt + 8 * j, 8);
+        bits = bswap64(bits);
+        double x;
+        std::memcpy(&x, &bits, 8);
+        out[j] = static_cast<float>(x);
+    }
+}
+#if defined(__x86_64__)
+// the same with 32-byte vectors: byte-reverse four doubles with one shuffle, narrow with one convert (chosen at run time)
+__attribute__((target("avx2"))) inline void decode_row_avx2(const unsigned char* pt, int dim, float* out) {
+    typedef long long v4di __attribute__((vector_size(32)));
+    typedef char v32qi __attribute__((vector_size(32)));
+    typedef double v4df __attribute__((vector_size(32)));
+    typedef float v4sf __attribute__((vector_size(16)));
+    const v32qi rev = {7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8};
+    int j = 0;
+    for (; j + 4 <= dim; j += 4) {
+        v4di raw;
+        std::memcpy(&raw, pt + 8 * j, 32);
+        const v32qi sw = __builtin_ia32_pshufb256(reinterpret_cast<v32qi>(raw), rev);
+        const v4sf f = __builtin_ia32_cvtpd2ps256(reinterpret_cast<v4df>(sw));
+        std::memcpy(out + j, &f, 16);
+    }
+    if (j < dim) decode_row(pt + 8 * j, dim - j, out + j);
+}
+__attribute__((target("avx2"))) inline void decode_row_avx2(const unsigned char* pt, int dim, double* out) {
+    typedef long long v4di __attribute__((vector_size(32)));
+    typedef char v32qi __attribute__((vector_size(32)));
+    const v32qi rev = {7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8};
+    int j = 0;
+    for (; j + 4 <= dim; j += 4) {
+        v4di raw;
+        std::memcpy(&raw, pt + 8 * j, 32);
+        const v32qi sw = __builtin_ia32_pshufb256(reinterpret_cast<v32qi>(raw), rev);
+        std::memcpy(out + j, &sw, 32);
+    }
+    if (j < dim) decode_row(pt + 8 * j, dim - j, out + j);
+}
+inline bool cpu_has_avx2() { static const bool v = __builtin_cpu_supports("avx2"); return v; }
+#else
+inline bool cpu_has_avx2() { return false; }
+template <typename T> inline void decode_row_avx2(const unsigned char* pt, int dim, T* out) { decode_row(pt, dim, out); }
+#endif
+template <typename T> inline void decode_row_fast(const unsigned char* pt, int dim, T* out) {
+    if (cpu_has_avx2()) decode_row_avx2(pt, dim, out); else decode_row(pt, dim, out);
+}
+
 // decryptFromPoint of one record into `out` (dim doubles, host byte order).  Retries while a writer holds the record.
-inline bool pointstore_open_one(fspann_pointstore* ps, GcmWorker& w, int64_t h, std::vector<unsigned char>& scratch, double* out, int* version_out) {
+template <typename TOut>
+inline bool pointstore_open_one(fspann_pointstore* ps, GcmWorker& w, int64_t h, std::vector<unsigned char>& scratch, TOut* out, int* version_out) {
     const int dim = ps->dim, ctlen = 8 * dim;
     if (h < 0 || h >= ps->n) return false;
     // A writer holds a record (version word -1) only while it copies ~1 KB, but on an oversubscribed host it can be
@@ -297,7 +392,7 @@ inline bool pointstore_open_one(fspann_pointstore* ps, GcmWorker& w, int64_t h, 
             unsigned char key[32];
             if (!ps->key_for(v, key) || !w.set_dec_key(v, key)) return false;        // retired key: the old ciphertext is unreadable by design
         }
-        copy_from_shared(scratch.data(), ps->rec(h) + 4, kIvBytes + ctlen + kTagBytes);   // snapshot, then re-check the version
+        copy_from_shared(scratch.data(), ps->rec(h) + kRecHeader, kIvBytes + ctlen + kTagBytes);   // snapshot, then re-check the version
         std::atomic_thread_fence(std::memory_order_acquire);                            // the copy's reads stay ahead of the re-check
         if (ps->ver(h)->load(std::memory_order_relaxed) != v) continue;
         char aad[96];
@@ -311,12 +406,7 @@ inline bool pointstore_open_one(fspann_pointstore* ps, GcmWorker& w, int64_t h, 
             if (++tag_failures <= 3) continue;
             return false;
         }
-        for (int j = 0; j < dim; j++) {                // deserializeVector
-            uint64_t bits;
-            std::memcpy(&bits, pt + 8 * j, 8);
-            bits = bswap64(bits);
-            std::memcpy(out + j, &bits, 8);
-        }
+        decode_row_fast(pt, dim, out);                 // deserializeVector
         if (version_out) *version_out = v;
         return true;
     }
@@ -353,8 +443,8 @@ inline int pointstore_reencrypt(fspann_pointstore* ps, const int32_t* handles, i
             int32_t expect = oldv;
             if (!ps->ver(h)->compare_exchange_strong(expect, -1, std::memory_order_acq_rel)) continue;   // someone else rewrote it meanwhile
             unsigned char* r = ps->rec(h);
-            copy_to_shared(r + 4, iv, kIvBytes);
-            copy_to_shared(r + 4 + kIvBytes, sealed.data(), static_cast<size_t>(ptlen) + kTagBytes);
+            copy_to_shared(r + kRecHeader, iv, kIvBytes);
+            copy_to_shared(r + kRecHeader + kIvBytes, sealed.data(), static_cast<size_t>(ptlen) + kTagBytes);
             ps->ver(h)->store(target, std::memory_order_release);
             done++;
         }
@@ -387,9 +477,12 @@ inline void pointstore_open_batch(fspann_pointstore* ps, int64_t nq, int64_t B, 
             int kept = 0;
             for (int j = 0; j < c; j++) {
                 const int32_t id = ids[q * B + j];
-                if (!pointstore_open_one(ps, w, id, scratch, row.data(), nullptr)) { badc++; continue; }
-                TOut* o = dst + (q * B + kept) * dim;
-                for (int t = 0; t < dim; t++) o[t] = static_cast<TOut>(row[t]);
+                if (j + 1 < c) {                                  // F_q's records are scattered over the store: the next one is requested now
+                    const int32_t nx = ids[q * B + j + 1];
+                    if (nx >= 0 && nx < ps->n) { const unsigned char* r = ps->rec(nx); for (size_t off = 0; off < ps->stride; off += 64) __builtin_prefetch(r + off, 0, 0); }
+                }
+                // decoded straight into the query's block (a failed open leaves the slot to the next survivor)
+                if (!pointstore_open_one(ps, w, id, scratch, dst + (q * B + kept) * dim, nullptr)) { badc++; continue; }
                 out_ids[q * B + kept] = id;
                 kept++;
                 okc++;

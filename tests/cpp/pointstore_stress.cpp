@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     if (!crypto_api()) { std::printf("libcrypto not found: skipped\n"); return 77; }
     fspann_pointstore ps;
     ps.n = n; ps.dim = dim;
-    ps.stride = (4 + kIvBytes + 8 * static_cast<size_t>(dim) + kTagBytes + 7) & ~size_t(7);
+    ps.stride = pointstore_stride(dim);
     ps.mem.assign(static_cast<size_t>(n) * ps.stride, 0);
     for (int i = 0; i < 32; i++) ps.master[i] = static_cast<unsigned char>(7 * i + 1);
     ps.have_master = true;
