@@ -26,6 +26,13 @@ import java.util.*;
  *   key        GreedyPartitioner.computeKey / hamming on given BitSets
  *   build      GreedyPartitioner.build on a small id->code map (partition ids, min/max keys, representative)
  *   cast       (int) Math.floor(x) saturation
+ *   route      ONE WHOLE lookupCandidatesWithScores list per line: partitions cut by GreedyPartitioner.build from a fixed id -> code
+ *              map (three tables of 24 000 decimal ids), then the literal loop of PartitionedIndexService.java:619-696 — HashMap
+ *              bestScore, PriorityQueue probing, HARD_CAP checks per probe step, stable sort by score — for two fixed queries under
+ *              four (HARD_CAP, probes) settings: one query's bestScore map TREEIFIES a bin (twelve ids of one bin of the 2 048-table,
+ *              on two score levels), two settings CROSS the HARD_CAP (one with a resize 128 -> 256 on the way).  No RocksDB, no
+ *              crypto: metadata.isDeleted is "nothing deleted".  This pins the ORDER the kernels derive in closed form, not just
+ *              the primitives behind it.
  */
 public final class GoldenDumper {
     public static void main(String[] args) {
@@ -103,6 +110,77 @@ public final class GoldenDumper {
             for (GreedyPartitioner.Partition p : parts)
                 System.out.println("build " + p.minKey + " " + p.maxKey + " " + Arrays.toString(p.repCode.toLongArray()).replaceAll("[\\[\\],]", "")
                         + " " + String.join(",", p.ids));
+        }
+        {   // route: see the class comment.  Scene = tests/golden/compare_jvm_dump.py route_scene(), number for number.
+            final int N = 24000, T = 3;
+            final long[] A = {7919L, 104729L, 1299709L}, B = {17L, 4242L, 31337L};
+            final long[] QA = {0x1234L, 0x0F0FL, 0x5555L}, QB = {0x8001L, 0x7FFEL, 0x00FFL};
+            long[][] code = new long[T][N];
+            for (int t = 0; t < T; t++)
+                for (int i = 0; i < N; i++) code[t][i] = (((long) i * A[t] + B[t]) % 65521L) & 0xFFFFL;
+            int crowded = 0;                          // the first twelve ids whose bin of a 2 048-slot table is 312: six beside QA in table 0,
+            for (int i = 0; i < N && crowded < 12; i++) {   //   six one bit away from QA in table 1 (another partition distance)
+                int h = Integer.toString(i).hashCode();
+                if (((h ^ (h >>> 16)) & 2047) == 312) {
+                    if (crowded < 6) code[0][i] = QA[0]; else code[1][i] = QA[1] ^ 0x8000L;
+                    crowded++;
+                }
+            }
+            List<List<GreedyPartitioner.Partition>> tables = new ArrayList<>();
+            for (int t = 0; t < T; t++) {
+                Map<String, BitSet> idToCode = new HashMap<>(N);
+                for (int i = 0; i < N; i++) idToCode.put(Integer.toString(i), BitSet.valueOf(new long[]{code[t][i]}));
+                tables.add(GreedyPartitioner.build(idToCode, 64));
+            }
+            final int[][] settings = {{1500, 5}, {100, 5}, {1500, 10}, {300, 5}};       // {HARD_CAP, perDivisionMaxProbes}
+            for (int[] st : settings) {
+                final int HARD_CAP = st[0], perDivisionMaxProbes = st[1];
+                for (int qn = 0; qn < 2; qn++) {
+                    final long[] q = qn == 0 ? QA : QB;
+                    // ---- PartitionedIndexService.java:619-687, literally (one division per table; nothing deleted) ----
+                    Map<String, Long> bestScore = new HashMap<>(Math.min(HARD_CAP, 1 << 16));
+                    int rawSeen = 0;
+                    for (int t = 0; t < T && bestScore.size() < HARD_CAP; t++) {
+                        List<GreedyPartitioner.Partition> parts = tables.get(t);
+                        BitSet qBits = BitSet.valueOf(new long[]{q[t]});
+                        long qKey = GreedyPartitioner.computeKey(qBits);
+                        int center = GreedyPartitioner.findNearestPartition(parts, qKey);
+                        PriorityQueue<long[]> probeQueue = new PriorityQueue<>(Comparator.comparingLong(a -> a[1]));
+                        boolean[] visited = new boolean[parts.size()];
+                        long centerDist = GreedyPartitioner.hamming(qBits, parts.get(center).repCode);
+                        probeQueue.add(new long[]{center, centerDist});
+                        visited[center] = true;
+                        int probesUsed = 0;
+                        while (!probeQueue.isEmpty() && probesUsed < perDivisionMaxProbes && bestScore.size() < HARD_CAP) {
+                            long[] cur = probeQueue.poll();
+                            int idx = (int) cur[0];
+                            probesUsed++;
+                            GreedyPartitioner.Partition p = parts.get(idx);            // collectPartitionOrdered (PIS:726-753)
+                            long partDist = GreedyPartitioner.hamming(qBits, p.repCode);
+                            for (String id : p.ids) {
+                                Long prev = bestScore.get(id);
+                                if (prev == null || partDist < prev) { bestScore.put(id, partDist); rawSeen++; }
+                            }
+                            int left = idx - 1;
+                            if (left >= 0 && !visited[left]) {
+                                visited[left] = true;
+                                probeQueue.add(new long[]{left, GreedyPartitioner.hamming(qBits, parts.get(left).repCode)});
+                            }
+                            int right = idx + 1;
+                            if (right < parts.size() && !visited[right]) {
+                                visited[right] = true;
+                                probeQueue.add(new long[]{right, GreedyPartitioner.hamming(qBits, parts.get(right).repCode)});
+                            }
+                        }
+                    }
+                    // ---- PIS:690-696: the map's entries in iteration order, stable-sorted by score ----
+                    List<Map.Entry<String, Long>> result = new ArrayList<>(bestScore.entrySet());
+                    result.sort(Comparator.comparingLong(Map.Entry::getValue));
+                    StringBuilder sb = new StringBuilder("route " + HARD_CAP + " " + perDivisionMaxProbes + " " + (qn == 0 ? "QA" : "QB") + " " + result.size() + " " + rawSeen);
+                    for (Map.Entry<String, Long> e : result) sb.append(' ').append(e.getKey()).append(':').append(e.getValue());
+                    System.out.println(sb);
+                }
+            }
         }
         {
             StringBuilder sb = new StringBuilder("cast");

@@ -65,8 +65,47 @@ def oracle_lines():
     for p in range(len(ix["min_key"])):
         ids = ix["ids"][ix["id_off"][p]:ix["id_off"][p + 1]]
         out.append("build %d %d %d %s" % (ix["min_key"][p], ix["max_key"][p], int(np.int64(ix["rep"][p, 0])), ",".join(str(int(i)) for i in ids)))
+    out.extend(route_lines())
     out.append("cast " + " ".join(str(O.d2i(float(np.floor(x)))) for x in (1e300, -1e300, float("nan"), 2147483647.5, -2147483648.5, -0.5, 3.99)))
     return out
+
+
+def route_scene():
+    """The `route` case of GoldenDumper.java, number for number: three tables of 24 000 decimal ids with 16-bit codes, twelve ids of
+    ONE bin of the 2 048-slot table placed beside query QA (six in table 0, six one bit away in table 1)."""
+    import ctypes as C
+    N, T = 24000, 3
+    A, B = (7919, 104729, 1299709), (17, 4242, 31337)
+    QA, QB = (0x1234, 0x0F0F, 0x5555), (0x8001, 0x7FFE, 0x00FF)
+    codes = np.zeros((N, T, 1), np.uint64)
+    i = np.arange(N, dtype=np.int64)
+    for t in range(T):
+        codes[:, t, 0] = ((i * A[t] + B[t]) % 65521) & 0xFFFF
+    h = O.decimal_hashes(N).view(np.uint32)
+    crowd = np.flatnonzero(((h ^ (h >> 16)) & 2047) == 312)[:12]
+    assert len(crowd) == 12
+    codes[crowd[:6], 0, 0] = QA[0]
+    codes[crowd[6:], 1, 0] = QA[1] ^ 0x8000
+    q = np.array([[[c] for c in QA], [[c] for c in QB]], np.uint64)
+    return N, T, codes, q, crowd, C
+
+
+def route_lines(with_flags=False):
+    N, T, codes, q, crowd, C = route_scene()
+    out, flags = [], []
+    for hard_cap, probes in ((1500, 5), (100, 5), (1500, 10), (300, 5)):
+        o = O.Oracle(T, 1, 8, 2, 1, max_global_candidates=hard_cap, refinement_limit=min(hard_cap, 64))
+        o.set_id_meta(N)
+        O.lib().orc_build_index(o._h, C.c_int64(N), np.arange(N, dtype=np.int32).ctypes.data_as(C.c_void_p), codes.ctypes.data_as(C.c_void_p))
+        ids, score, count, raw = o.route(q, probe_override=probes)
+        tree = o.route_treeified(q, probe_override=probes)
+        assert not o.unmodelled
+        for qi, qn in enumerate(("QA", "QB")):
+            n = int(count[qi])
+            out.append("route %d %d %s %d %d " % (hard_cap, probes, qn, n, int(raw[qi])) +
+                       " ".join("%d:%d" % (int(ids[qi, k]), int(score[qi, k])) for k in range(n)))
+            flags.append((hard_cap, probes, qn, bool(tree[qi]), n))
+    return (out, flags) if with_flags else out
 
 
 def main():

@@ -175,3 +175,44 @@ def test_nan_vector_rejected(oracle):
         oracle.H(np.array([0.0, np.nan, 0, 0]), alpha, r, w)
     with pytest.raises(ValueError):
         oracle.Ccode(np.array([0.0, np.inf, 0, 0]), alpha, r, w, 2)
+
+
+def test_jvm_dump_comparer_round_trips_and_its_route_scene_means_what_it_says(tmp_path):
+    """tests/golden/compare_jvm_dump.py is what meets a JVM one day (java/com/fspann/gpu/GoldenDumper.java): the comparer must
+    accept the oracle's own lines, reject a reordered list, and the `route` scene must really contain what its comment claims —
+    a query whose bestScore map treeifies (and whose list is NOT in insertion order), HARD_CAP crossings with and without a
+    resize — or a green JVM run would pin less than it says (missing #1)."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compare_jvm_dump.py")
+    spec = importlib.util.spec_from_file_location("compare_jvm_dump", path)
+    cmp_ = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cmp_)
+    lines = cmp_.oracle_lines()
+    routes = [l for l in lines if l.startswith("route ")]
+    assert len(routes) == 8
+    _, flags = cmp_.route_lines(with_flags=True)
+    by = {(hc, p, qn): (tree, n) for hc, p, qn, tree, n in flags}
+    assert by[(1500, 5, "QA")][0] and not by[(1500, 5, "QB")][0]                 # one map treeifies, the other stays chains
+    assert by[(1500, 10, "QA")][0]
+    assert by[(100, 5, "QA")][1] == 128 and by[(300, 5, "QB")][1] == 320         # HARD_CAP crossed after whole probe steps (PIS:657-659)
+    assert not by[(100, 5, "QA")][0]                                             # ... before the ninth id of the bin arrived
+    # all twelve crowded ids are in QA's list, on two score levels, in the tree bin's order
+    N, T, codes, q, crowd, _ = cmp_.route_scene()
+    qa = [int(x.split(":")[0]) for x in routes[0].split()[6:]]
+    in_list = [i for i in qa if i in set(int(c) for c in crowd)]
+    assert len(in_list) == 12 and in_list != sorted(in_list)       # (and the oracle's own flag above says why: a tree bin)
+    dump = tmp_path / "jvm.txt"
+    dump.write_text("\n".join(lines) + "\n")
+    ok = subprocess.run([sys.executable, path, str(dump)], capture_output=True, text=True)
+    assert ok.returncode == 0 and "PINNED" in ok.stdout, ok.stdout[-500:]
+    # a JVM that ordered one treeified bin differently must FAIL the comparison
+    toks = routes[0].split()
+    k = next(i for i in range(6, len(toks) - 1) if toks[i].split(":")[1] == toks[i + 1].split(":")[1])
+    toks[k], toks[k + 1] = toks[k + 1], toks[k]
+    bad_lines = [(" ".join(toks) if l is routes[0] else l) for l in lines]
+    dump.write_text("\n".join(bad_lines) + "\n")
+    bad = subprocess.run([sys.executable, path, str(dump)], capture_output=True, text=True)
+    assert bad.returncode == 1 and "MISMATCH" in bad.stdout
