@@ -1,0 +1,142 @@
+// api_encode.hip.h — TokenGen / Setup coding entry points: fspann_encode[_dev], the encode path switch (Coding.H / Coding.C, idx/Coding.java:250-301)
+// Part of the single translation unit fspann_api.hip (included there, in order); product code, no CPU fallback.
+#pragma once
+
+namespace {
+
+template <typename TIn>
+int launch_encode_mfma(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_dev, int32_t* hashes_dev, int32_t* bad_dev) {
+    const int P = c->P_total, d = c->cfg.dim;
+    const int64_t cap = std::max<int64_t>(65536, nq * P / 16);
+    int rc = ensure(c, c->ws_fix, 256 + static_cast<size_t>(cap) * 8);
+    if (rc) return rc;
+    unsigned long long* cnt = static_cast<unsigned long long*>(c->ws_fix.p);
+    int64_t* list = reinterpret_cast<int64_t*>(static_cast<char*>(c->ws_fix.p) + 256);
+    FSP_HIP(hipMemsetAsync(cnt, 0, 8, c->stream));
+    // the code words start clear: the MFMA epilogue ORs in the bits of the pairs it can decide, encode_fix_kernel those of the rest
+    FSP_HIP(hipMemsetAsync(codes_dev, 0, static_cast<size_t>(nq) * c->TD * c->W * 8, c->stream));
+    dim3 grid(static_cast<unsigned>((nq + kMfmaTileQ - 1) / kMfmaTileQ), static_cast<unsigned>((P + kMfmaTileP - 1) / kMfmaTileP));
+    unsigned long long* cw = reinterpret_cast<unsigned long long*>(codes_dev);
+    hipLaunchKernelGGL((encode_mfma_kernel<TIn>), grid, dim3(256), 0, c->stream, q_dev, nq, d, c->d_alphaT32, c->d_r, c->d_omega, P, c->cfg.m, c->cfg.lambda,
+                       c->W, c->TD, hashes_dev, cw, bad_dev, list, cap, cnt, c->alpha_norm_max);
+    FSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL((encode_fix_kernel<TIn>), dim3(static_cast<unsigned>(std::min<int64_t>(1024, (cap + 255) / 256))), dim3(256), 0, c->stream,
+                       q_dev, d, c->d_alphaT, c->d_r, c->d_omega, P, c->cfg.m, c->cfg.lambda, c->W, c->TD, list, cnt, cap, hashes_dev, cw);
+    FSP_HIP(hipGetLastError());
+    c->fix_cap_last = static_cast<unsigned long long>(cap);
+    return 1;  // caller enqueues the exact kernel guarded by (count > cap): it only runs if the list overflowed
+}
+
+template <typename TIn>
+int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_dev, int32_t* hashes_dev,
+                  int32_t* bad_dev, double* proj_dev = nullptr) {
+    const int m = c->cfg.m;
+    const unsigned long long* guard = nullptr;
+    unsigned long long guard_cap = 0;
+    const bool want_mfma = (c->encode_mode == 2) || (c->encode_mode == 0 && nq >= 4096);
+    if (want_mfma && !proj_dev && c->d_alphaT32 && c->W <= 3) {      // (the fused bit-pack epilogue carries three code words: <= 192 bits)
+        int rc = launch_encode_mfma<TIn>(c, nq, q_dev, codes_dev, hashes_dev, bad_dev);
+        if (rc <= 0) return rc;  // error
+        // the list can only overflow when almost every pair sits on a bucket boundary (degenerate omega): the
+        // exact kernel below is enqueued with a device-side guard and returns immediately otherwise.
+        guard = static_cast<const unsigned long long*>(c->ws_fix.p);
+        guard_cap = c->fix_cap_last;
+        c->mfma_last = true;
+    } else {
+        c->mfma_last = false;
+    }
+    const int tdPerBlock = std::max(1, kEncThreads / m);
+    const int gy = (c->TD + tdPerBlock - 1) / tdPerBlock;
+    const EncodeArgs<TIn> ea{q_dev, nq, c->cfg.dim, c->d_alphaT, c->d_r, c->d_omega, c->P_total, m, c->cfg.lambda, c->W, c->TD, tdPerBlock,
+                             codes_dev, hashes_dev, bad_dev, proj_dev, guard, guard_cap, c->dbg_route};
+    // QB queries per block: 8 for bulk coding (index build), 4 for query batches so that
+    // a 1024-query batch still fills 256 CUs.
+    bool launched = false;
+    if constexpr (sizeof(TIn) == 4) {       // (8 fp64 query rows per block do not fit the register budget)
+        if (nq >= 8192) {
+            constexpr int QB = 8;
+            hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        // 4 rows per workgroup = 256 workgroups for a 1024-query batch.  Every workgroup reads all of alpha (256 KB) from L2:
+        // fewer rows per workgroup (2: 12.8 us, 1: 20 us) cost more in that traffic than the extra waves per SIMD buy, and the
+        // loop itself is bound by one dependent fp64 instruction per ~10 cycles of a lone wave (7.8 of 11.4 us, tools/encode_stamps.py).
+        constexpr int QB = 4;
+        hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
+    }
+    FSP_HIP(hipGetLastError());
+    return FSPANN_OK;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+// ---- encode -----------------------------------------------------------------------
+int fspann_encode_dev(fspann_ctx* c, int64_t nq, const void* q_dev, int dtype, uint64_t* codes_dev,
+                      int32_t* hashes_dev, int32_t* bad_dev) {
+    CHECK_CTX(c);
+    if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized. Build index first.");
+    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    if (nq == 0) return FSPANN_OK;
+    if (!q_dev || !codes_dev) return fail(FSPANN_E_NULL, "query vector is null");
+    if (dtype == FSPANN_F64) return launch_encode<double>(c, nq, static_cast<const double*>(q_dev), codes_dev, hashes_dev, bad_dev);
+    if (dtype == FSPANN_F32) return launch_encode<float>(c, nq, static_cast<const float*>(q_dev), codes_dev, hashes_dev, bad_dev);
+    return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+}
+
+int fspann_encode(fspann_ctx* c, int64_t nq, const void* q, int dtype, uint64_t* codes, int32_t* hashes) {
+    CHECK_CTX(c);
+    if (!c->have_g) return fail(FSPANN_E_STATE, "GFunctionRegistry not initialized. Build index first.");
+    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    if (nq == 0) return FSPANN_OK;
+    if (!q || !codes) return fail(FSPANN_E_NULL, "query vector is null");
+    if (dtype != FSPANN_F32 && dtype != FSPANN_F64) return fail(FSPANN_E_ARG, "unknown dtype %d", dtype);
+    const size_t esz = dtype == FSPANN_F64 ? 8 : 4;
+    const size_t qb = static_cast<size_t>(nq) * c->cfg.dim * esz;
+    const size_t cb = static_cast<size_t>(nq) * c->TD * c->W * 8;
+    const size_t hb = hashes ? static_cast<size_t>(nq) * c->P_total * 4 : 0;
+    return guarded([&]() -> int {
+    int rc;
+    if ((rc = ensure(c, c->ws_io[0], qb))) return rc;
+    if ((rc = ensure(c, c->ws_io[1], cb))) return rc;
+    if ((rc = ensure(c, c->ws_io[2], static_cast<size_t>(nq) * 4))) return rc;
+    if (hashes && (rc = ensure(c, c->ws_io[3], hb))) return rc;
+    FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, q, qb, hipMemcpyHostToDevice, c->stream));
+    rc = fspann_encode_dev(c, nq, c->ws_io[0].p, dtype, static_cast<uint64_t*>(c->ws_io[1].p),
+                           hashes ? static_cast<int32_t*>(c->ws_io[3].p) : nullptr, static_cast<int32_t*>(c->ws_io[2].p));
+    if (rc) return rc;
+    std::vector<int32_t> bad(static_cast<size_t>(nq));
+    FSP_HIP(hipMemcpyAsync(codes, c->ws_io[1].p, cb, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipMemcpyAsync(bad.data(), c->ws_io[2].p, static_cast<size_t>(nq) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (hashes) FSP_HIP(hipMemcpyAsync(hashes, c->ws_io[3].p, hb, hipMemcpyDeviceToHost, c->stream));
+    FSP_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < nq; i++)
+        if (bad[i]) return fail(FSPANN_E_ARG, "Vector contains NaN/Inf (query %lld)", (long long)i);  // Coding.java:360
+    return FSPANN_OK;
+    });
+}
+
+// Encode path selection: 0 = auto (MFMA pre-filter for nq >= 4096, exact fp64 otherwise), 1 = exact fp64 VALU only,
+// 2 = always MFMA fp32 GEMM + exact re-check.  All modes produce bit-identical hashes and codes.
+int fspann_set_encode_mode(fspann_ctx* c, int mode) {
+    if (!c) return fail(FSPANN_E_NULL, "ctx is null");
+    if (mode < 0 || mode > 2) return fail(FSPANN_E_ARG, "encode mode must be 0, 1 or 2");
+    c->encode_mode = mode;
+    return FSPANN_OK;
+}
+// (query, projection) pairs the last MFMA-path encode re-checked with the exact kernel (0 for the exact path).
+int64_t fspann_last_encode_rechecked(fspann_ctx* c) {
+    if (!c) return FSPANN_E_NULL;
+    if (!c->mfma_last || !c->ws_fix.p) return 0;
+    unsigned long long n = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(&n, c->ws_fix.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return FSPANN_E_DEVICE;
+    return static_cast<int64_t>(n);
+}
+
+
+}  // extern "C"

@@ -146,6 +146,10 @@ __device__ __forceinline__ void refine_topk_emit(const RefineArgs<TC, TQ>& a, TC
         // below (T + 2^kCutLow) << 32.  One vector compare per step, the rest is scalar work — this epilogue is the tail of
         // the launch, every wave of a SIMD is in it at once and they share one vector pipe (an exact all-pairs rank of the
         // wave's 64 keys: ~400 vector instructions per wave, 1.5 us of the launch).
+        // NOTE on the inline asm below and in the survivor masks: v_cmp_*_e64 writes its lane mask into an arbitrary scalar pair, and the
+        // compiler's hazard recogniser does not see that write as a VALU write of an SGPR.  The masks may therefore only feed scalar ALU
+        // and plain vector instructions (s_bcnt, mbcnt, shifts — what they feed today); used as a VMEM scalar operand or a readlane /
+        // writelane selector they would need the 4-5 wait states of the gfx9 "VALU writes SGPR" hazards inserted by hand.
         // (compares through the icmp builtin: its result IS the lane mask in scalar registers — one vector instruction and
         // four scalar ones per candidate; __ballot of a bool costs two more vector instructions, and every hop between
         // the vector and scalar pipes is a pipeline latency on this dependent chain: 1.5 us of the launch's tail as 21
@@ -874,18 +878,29 @@ __global__ __launch_bounds__(256) void refine_merge_kernel(const RefinePartial* 
     if constexpr (KEYS_IN_LDS)
         for (int e = tid; e < nelem; e += blockDim.x) s_keys[e] = partial[qi * nelem + e].key;     // entries beyond a list's length are never read
     __syncthreads();
-    const int j = (k + nchunks - 1) / nchunks;
+    // Only lists that HOLD j keys can vouch for j keys at or below the cut.  A query with fewer candidates than B leaves trailing
+    // lists empty or short (the common partial-count case): with m lists of at least ceil(k / nchunks) keys, j = ceil(k / m) is tried —
+    // the lists holding j vouch, and the cut stands when they vouch for k between them; the shorter lists are searched like the others.
+    __shared__ int s_m;
+    const int j0 = (k + nchunks - 1) / nchunks;
+    if (tid == 0) s_m = 0;
+    __syncthreads();
     for (int c = tid; c < nchunks; c += blockDim.x) {
         const int cc = partial_cnt[(qi * nchunks + c) * 2];
         s_pref[c] = cc;                                            // the list's length until the cut is known
         atomicAdd(&s_total, cc);
         atomicAdd(&s_nvalid, partial_cnt[(qi * nchunks + c) * 2 + 1]);
-        if (cc < j) atomicAdd(&s_short, 1);                        // a list too short to vouch for j keys: no cut
-        else atomicMax(&s_cut, static_cast<unsigned long long>(key_at(c, j - 1)));
+        if (cc >= j0) atomicAdd(&s_m, 1);
+    }
+    __syncthreads();
+    const int j = s_m > 0 ? (k + s_m - 1) / s_m : 0;
+    for (int c = tid; c < nchunks; c += blockDim.x) {
+        const int cc = s_pref[c];
+        if (j > 0 && cc >= j) { atomicAdd(&s_short, 1); atomicMax(&s_cut, static_cast<unsigned long long>(key_at(c, j - 1))); }   // s_short: lists that vouch
     }
     __syncthreads();
     const int eff = min(k, s_total);
-    if (s_short == 0) {                                            // every list holds >= j keys <= cut: >= k in all
+    if (j > 0 && static_cast<long long>(s_short) * j >= k) {        // the vouching lists hold >= k keys <= cut between them
         const uint64_t cut = s_cut;
         for (int c = tid; c < nchunks; c += blockDim.x) {
             int lo = 0, hi = s_pref[c];                            // first index with key > cut

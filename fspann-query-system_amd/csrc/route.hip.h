@@ -1004,7 +1004,12 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             uint32_t* slice = gsort + static_cast<size_t>(wave) * wcap;
             // Every wave on its own: wave w takes the groups w, w + waves, ... (ascending, so it may stop at the first one behind the
             // limit).  (Groups handed out through an LDS counter — `if (lane == 0) g = atomicAdd(..)` + broadcast inside a loop with
-            // continue / break — hung the GPU: the compiler's structurised loop went on with lane 0 masked off and g = 0 for ever.)
+            // continue / break — hung the GPU.  The ISA of the reduced case, tools/micro/lane0_loop.hip: the structurised loop takes
+            // lanes out of EXEC one by one at its latch (s_andn2_b64 exec, exec, <left>), and the broadcast is a ds_bpermute from
+            // lane 0, which reads 0 from a lane that is not in EXEC — so as soon as lane 0 has left and another lane has not, the
+            // rest re-run group 0 for ever.  The idiom needs every exit to be wave-uniform at run time; the variant that hung had
+            // a per-lane exit in front of the broadcast.  The remaining lane-0-atomic + broadcast sites — the compaction above and two
+            // in route_lazy.hip.h — sit in loops whose trip counts come from scalar / LDS values behind a barrier.)
             const int wave_s = __builtin_amdgcn_readfirstlane(wave);
             bool any_big = false;
             for (int g = wave_s; g < ngrp; g += nwv) {

@@ -1,4 +1,4 @@
-// host_mirror_test.cpp — drives the C++ operator mirror (fspann-query-system_amd/host/fspann_host.hpp) the way
+// host_mirror_test.cpp — drives the C++ operator mirror (tests/cpp/fspann_host.hpp: test infrastructure, the tested twin of the product is operators.py) the way
 // ForwardSecureANNSystem does (FSA:479-570 batchInsert, :622-748 runQueries): insert -> finalizeForSearch ->
 // createToken -> search, and dumps results for tests/test_gpu_cpp_host.py to compare with the golden fixtures.
 // Also checks the error behaviour of the operator surface (it/.../SuperFailureModeIT.java:11-46).
@@ -12,7 +12,7 @@
 #include <cstring>
 #include <map>
 
-#include "../../fspann-query-system_amd/host/fspann_host.hpp"
+#include "fspann_host.hpp"
 
 using namespace fspann::host;
 

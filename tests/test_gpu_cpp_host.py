@@ -1,4 +1,4 @@
-"""GPU: the C++ host mirror of the operator surface (host/fspann_host.hpp) — compiled with g++ against
+"""GPU: the C++ host mirror of the operator surface (tests/cpp/fspann_host.hpp) — compiled with g++ against
 libfspann_hip.so and driven like ForwardSecureANNSystem drives the Java operators; results are compared with
 the golden fixtures (oracle restatement of QSI.search, incl. the adaptive retry and the getLast* metrics)."""
 import os

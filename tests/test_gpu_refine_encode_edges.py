@@ -67,6 +67,9 @@ def test_refine_topk_epilogue_corner_cases(pkg, oracle):
     cand[2] = q[2] + np.outer(mags, np.eye(d)[0])
     cand[3, :, 0] = np.where(np.arange(B) % 64 < 3, cand[3, :, 0], np.nan)     # three valid rows per wave
     cand[4, 64:, 1] = np.inf                                        # only the first wave holds valid rows
+    # 256 DIFFERENT distances inside one 2^-10 bucket of the bisected top word: all 256 survive the cut (T = 256, one lane per
+    # survivor, no partial counts to meet) and the order is decided by the low bits alone
+    cand[5] = q[5] + np.outer(1.0 + np.arange(B)[::-1] * 1e-7, np.eye(d)[1])
     ids = np.tile(np.arange(B, dtype=np.int32), (6, 1))
     cnt = np.full(6, B, np.int32)
     for k in (1, 5, 10, 32, 33):
@@ -118,6 +121,19 @@ def test_refine_running_topk_over_runs_of_chunks(pkg, oracle, nq, B, k):
         cnt[2] = 257                                            # one full chunk and one row
     for dt in (np.float32, np.float64):
         _check_refine(pkg, oracle, q, cand, ids, cnt, k, dt)
+
+
+def test_refine_merge_with_partial_counts(pkg, oracle):
+    """k <= 32 over several chunks = one list per chunk + refine_merge_kernel; cand_count < B leaves trailing lists empty or short:
+    the cut is then vouched for by the lists that hold enough keys (it used to be dropped altogether) — same results."""
+    rng = np.random.default_rng(5)
+    nq, B, d, k = 12, 2048, 16, 20
+    q = rng.standard_normal((nq, d))
+    cand = rng.standard_normal((nq, B, d))
+    ids = rng.integers(0, 10**6, (nq, B)).astype(np.int32)
+    cnt = np.array([B, 257, 300, 512, 513, 1000, 19, 20, 21, 256, 1025, 0], np.int32)
+    _check_refine(pkg, oracle, q, cand, ids, cnt, k)
+    _check_refine(pkg, oracle, q, cand, ids, cnt, 7)
 
 
 def test_refine_nonfinite(pkg, oracle):
