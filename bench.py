@@ -1059,6 +1059,9 @@ def main():
     else:
         f64_rows = None
     kname = "refine_stream_kernel<float,float,32,%s>" % ("true" if mode == "store" else "false")
+    if mode != "store" and B > 256 and 32 < k <= 128:
+        kname = ("refine_stream_kernel<float,float,32,false,true> (a workgroup walks a run of consecutive chunks of one query and keeps its best k "
+                 "in LDS: one list per run, no merge kernel when a run is the whole query)")
     if args.pipeline == "front" and not use_tick and mode == "dense" and B <= 256:
         kname = "refine_stream_fix_kernel<false> (the streaming scan whose workgroups first finish queries the bounded select handed over)"
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, peak_spec=HBM_PEAK_GBS,
