@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-KERNEL = "refine_stream_kernel<float, float, 32, false>"
+KERNEL = "refine_stream_kernel<float, float, 32, false"      # (round 4: ..., false, false> — the template gained the runs-of-chunks switch)
 
 
 def avg(counter):
@@ -33,13 +33,13 @@ alg = Q * (B * d * 4 + d * 4 + k * 8)
 path = os.path.join(ROOT, "profiles", "refine_traffic.json")
 j = json.load(open(path)) if os.path.exists(path) else {}
 j["dense"] = {
-    "workload": "sift1m_T16_b32_B256_Q1024", "Q": Q, "kernel": KERNEL.replace(", ", ","),
+    "workload": "sift1m_T16_b32_B256_Q1024", "Q": Q, "kernel": "refine_stream_kernel<float,float,32,false,false>",
     "hbm_bytes_per_launch": int(round((2 * fetch_kb + write_kb) * 1024)),
     "FETCH_SIZE_KB_avg": round(fetch_kb, 1), "WRITE_SIZE_KB_avg": round(write_kb, 1), "launches": n,
     "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced (16 B/lane) streaming read -> x2 "
                   "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; units KB = 1024 B",
     "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv, profiles/{tag}_pmc_WRITE_SIZE.csv (separate rocprofv3 --kernel-trace --pmc passes of "
-              "`python3 bench.py --no-cpu-baseline --no-extras --pipeline serial --steps 10 --warmup 2`; 32 dense blocks = 4.3 GB cycled, "
+              "`python3 bench.py --no-cpu-baseline --no-extras --no-shipped --pipeline serial --steps 10 --warmup 2`; 32 dense blocks = 4.3 GB cycled, "
               "so the rows come from HBM)",
     "algorithmic_bytes_per_launch": alg,
 }
