@@ -263,7 +263,11 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
     c->last_route_lazy = pl.lazy;
     if (pl.lazy) {
         if (pl.lz_entries == 512) {
-            hipLaunchKernelGGL((route_select_lazy_kernel<kLzThreads, 512, false>), dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
+            // (the shape of BASELINE configs #2 / #3 — 16 tables x 5 probes, blocks of 64 — has a build with the shape as constants)
+            if (c->knob_shape_spec && c->TD == 16 && pl.P == 5 && pl.S == 64 && c->W == 1 && c->rec_words == 4 && (p.probe_G == 16 || p.probe_G == 0))
+                hipLaunchKernelGGL((route_select_lazy_kernel<kLzThreads, 512, false, 16, 5>), dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
+            else
+                hipLaunchKernelGGL((route_select_lazy_kernel<kLzThreads, 512, false>), dim3(pl.lz_grid), dim3(kLzThreads), pl.lz_lds_bytes, c->stream, p);
         } else if (pl.lz_entries == 2048) {
             auto lk = route_select_lazy_kernel<kLzThreads, 2048, true>;
             if (!(c->attr_mask & 1024u)) {

@@ -235,7 +235,10 @@ int fspann_tick_dev(fspann_ctx* c, const fspann_tick* t) {
     };
     if (front && (plR.lz_entries == 512 || plR.lz_entries == kLzEntriesMax)) {
         if (plR.lz_entries == 512) {
-            hipLaunchKernelGGL((front_kernel<512, false>), dim3(static_cast<unsigned>(total)), dim3(kTickThreads), lds, c->stream, p, eaT, routeT);
+            if (c->knob_shape_spec && c->TD == 16 && plR.P == 5 && plR.S == 64 && c->W == 1 && c->rec_words == 4 && (routeT.probe_G == 16 || routeT.probe_G == 0))
+                hipLaunchKernelGGL((front_kernel<512, false, 16, 5>), dim3(static_cast<unsigned>(total)), dim3(kTickThreads), lds, c->stream, p, eaT, routeT);
+            else
+                hipLaunchKernelGGL((front_kernel<512, false>), dim3(static_cast<unsigned>(total)), dim3(kTickThreads), lds, c->stream, p, eaT, routeT);
         } else {
             auto fk = front_kernel<kLzEntriesMax, true>;
             if (!(c->attr_mask & 2048u)) {

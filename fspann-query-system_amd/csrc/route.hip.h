@@ -277,10 +277,11 @@ __device__ __forceinline__ int route_probe_replay(const RouteTable& tb, const in
 // PIS.lookupCandidatesWithScores visits for this table, in the reference's order.  `act` = the group has a table to work on
 // (every lane of the wave must call: ballots inside).  w3 = LDS scratch of the group, (2P-1)*3 ints.  The list goes to
 // po[0..np) (LDS or global); returns np.
-template <typename OutPtr>
+// kP / kW (0 = run-time values): probes per table and code words as constants (the shape-specialised bounded select, route_lazy.hip.h).
+template <typename OutPtr, int kP = 0, int kW = 0>
 __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool act, const uint64_t* qc, const RouteTable tb, int G, int gl,
                                                  int grp_in_wave, int32_t* w3, OutPtr po) {
-    const int W = prm.W, P = prm.P;
+    const int W = kW > 0 ? kW : prm.W, P = kP > 0 ? kP : prm.P;
     const int nd = 2 * P - 1;
     act = act && tb.nparts > 0;
     // G is a power of two (both callers): shifts instead of divisions by a run-time value — a 32-bit division is ~25 vector
@@ -290,7 +291,7 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gshift);
     // GreedyPartitioner.computeKey: code bit i -> key bit 62-i (i < 63)
     const int64_t qKey = act ? static_cast<int64_t>(__brevll(qc[0]) >> 1) : 0;
-    const int RW = prm.rec_words;
+    const int RW = kW > 0 ? ((3 + kW + 1) & ~1) : prm.rec_words;     // (= the host's rec_words for W code words)
     const int64_t* recs = prm.recs + tb.part_base * RW;     // this table's partition records
     // a = first partition with maxKey >= qKey ; e = first partition with minKey > qKey.
     // Invariant of both searches: answer in [lo, hi], hi == nparts or pred(hi) true.

@@ -93,7 +93,11 @@ __device__ __forceinline__ int wave_cut1024(const int32_t* bins, int need, int l
 // kChk: built with the exact treeify check (step 0; it runs when prm.bin16 is set).  A template parameter because the check's
 // loads live across the ordering step: in the 512-entry class (80 registers at six workgroups per CU) they would spill, and any
 // scratch use costs every dispatch of the stream — that class is built without it, and a checked Route takes the 1024-entry class.
-template <int kThreads, int kEnt = kLzEntriesMax, bool kChk = true>
+// kTD / kP (0 = run-time values): the tables x probes shape as compile-time constants.  With them every LDS array base, trip count
+// and division by T*D*P below is an immediate; left to run time the kernel computes ~60 scalars in its prologue, keeps them for the
+// whole query and — beyond the 102 scalar registers it has — parks them in vector-register lanes (v_writelane / v_readlane).
+// The host launches the specialised build for BASELINE config #2 / #3's shape (16 tables x 5 probes, blocks of 64).
+template <int kThreads, int kEnt = kLzEntriesMax, bool kChk = true, int kTD = 0, int kP = 0>
 __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned char* smem, const int64_t q_first, const int64_t q_stride, const int block_id) {
     int4* probe_in = prm.probe_g;          // not __restrict__: a handed-over query's lists are written here and read back
     int32_t* nprobe_in = prm.nprobe_g;
@@ -101,7 +105,7 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
     constexpr int nthreads = kThreads;
     constexpr int nwv = kThreads / 64;
     int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: a scalar — what derives from it is scalar work
-    const int TD = prm.TD, P = prm.P, S = prm.S;
+    const int TD = kTD > 0 ? kTD : prm.TD, P = kP > 0 ? kP : prm.P, S = (kTD > 0) ? 64 : prm.S;
     const int TP = TD * P;
     const int SP = (S + 63) >> 6;                 // 64-lane pieces per partition
 
@@ -240,15 +244,16 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
         // ---- probe list of this query; unused steps get an impossible partition and sort last ------------------
         if (prm.probe_G > 0) {
             // fused probe (route_probe_table): one group of G lanes per table, all tables of the query side by side
-            const int G = prm.probe_G, lgG = 31 - __clz(G), ngroups = nthreads >> lgG;      // G: a power of two
+            const int G = (kTD > 0) ? 16 : prm.probe_G, lgG = 31 - __clz(G), ngroups = nthreads >> lgG;      // G: a power of two (16 whenever the probe is fused)
             const int grp_in_wave = lane >> lgG, gl = lane & (G - 1), grp = tid >> lgG;
             int32_t* w3 = reinterpret_cast<int32_t*>(pre) + grp * (2 * P - 1) * 3;     // `pre` is free until the rank pass
             for (int t0 = 0; t0 < TD; t0 += ngroups) {                                 // block-uniform trip count
                 const int td = t0 + grp;
                 const bool act = td < TD;
                 const int tdc = act ? td : 0;
-                const int np = route_probe_table(prm, act, prm.codes + (qi * TD + tdc) * prm.W, prm.tables[tdc], G, gl, grp_in_wave,
-                                                 w3, plist + tdc * P);
+                const int Wc = (kTD > 0) ? 1 : prm.W;
+                const int np = route_probe_table<int4*, kP, (kTD > 0 ? 1 : 0)>(prm, act, prm.codes + (qi * TD + tdc) * Wc, prm.tables[tdc], G, gl, grp_in_wave,
+                                                                             w3, plist + tdc * P);
                 if (act && gl == 0) nprobe_l[td] = np;
             }
             __syncthreads();
@@ -759,10 +764,10 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
 #undef LZ_INSERT
 }
 
-template <int kThreads, int kEnt, bool kChk>
+template <int kThreads, int kEnt, bool kChk, int kTD = 0, int kP = 0>
 __global__ __launch_bounds__(kThreads, (kEnt <= 512 ? 6 : (kEnt <= 1024 ? 4 : 2))) void route_select_lazy_kernel(RouteParams prm) {
     extern __shared__ __align__(16) unsigned char smem[];
-    route_lazy_run<kThreads, kEnt, kChk>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
+    route_lazy_run<kThreads, kEnt, kChk, kTD, kP>(prm, smem, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(gridDim.x), static_cast<int>(blockIdx.x));
 }
 
 }  // namespace fspann

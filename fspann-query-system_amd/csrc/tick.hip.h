@@ -110,12 +110,12 @@ __global__ __launch_bounds__(kTickThreads, 4) void tick_kernel(const TickHead h,
 // Refine role the launch needs only the bounded select's LDS and registers — in its 512-entry class 19.6 KB and 80 registers, six
 // workgroups per CU — and the encode workgroups (one wave per SIMD, bound by the issue rate of a lone wave) fill slots beside
 // the Route workgroups instead of holding the chip for a launch of their own.
-template <int kEnt, bool kChk>
+template <int kEnt, bool kChk, int kTD = 0, int kP = 0>
 __global__ __launch_bounds__(kTickThreads, (kEnt <= 512 ? 6 : 4)) void front_kernel(const TickHead h, const EncodeArgs<float> enc, const RouteParams route) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int b = static_cast<int>(blockIdx.x);
     if (b < h.n_enc) encode_exact_block<float, kTickEncQB>(enc, b % h.enc_gx, b / h.enc_gx, reinterpret_cast<int32_t*>(smem));
-    else route_lazy_run<kLzThreads, kEnt, kChk>(route, smem, b - h.n_enc, h.n_route, b - h.n_enc);
+    else route_lazy_run<kLzThreads, kEnt, kChk, kTD, kP>(route, smem, b - h.n_enc, h.n_route, b - h.n_enc);
 }
 
 // The stand-alone streaming scan (refine_stream_kernel) for a batch whose Route ran with a hand-over buffer: every workgroup
