@@ -264,6 +264,47 @@ def test_bounded_select_hands_back_large_queries(pkg, oracle, monkeypatch):
     assert LAZY_RUNS[-1]["overflowed"] > 0
 
 
+@pytest.mark.parametrize("case", ["plain", "runs_of_equal_keys", "long_runs", "tiny", "far_queries", "clustered", "deleted", "two_divisions"])
+def test_bounded_select_shape_specialised_build(pkg, oracle, case):
+    """16 tables x 5 probes, one code word, blocks of 64, limit <= 256: the bounded select's build with the shape as compile-time
+    constants (route_lazy.hip.h: kTD / kP).  The rarely-taken paths of the probe and the walk at exactly that shape: runs of equal
+    keys spanning partitions (a < b: the replayed binary search picks the centre), runs longer than the window, tables with
+    fewer partitions than the window, query keys below / above every partition and in gaps between partitions, deleted ids, two
+    divisions per table — all against the oracle, full select and bounded select."""
+    kw = dict(n=40000, d=16, T=16, D=1, m=12, lam=2, B=256, seed=900)
+    scale = 1.0
+    if case == "runs_of_equal_keys":
+        kw.update(m=4, seed=901)             # 8-bit codes: ~156 points per key -> runs over 2-3 partitions
+    elif case == "long_runs":
+        kw.update(m=3, n=60000, seed=902)    # 6-bit codes: ~940 points per key -> runs of ~15 partitions, beyond the window
+    elif case == "tiny":
+        kw.update(n=300, B=64, seed=903)     # five partitions per table: fewer than the 11-record window
+    elif case == "far_queries":
+        kw.update(seed=904)
+        scale = 40.0                         # saturated projections: keys at and beyond the tables' ends
+    elif case == "clustered":
+        kw.update(clustered=True, seed=905)
+    elif case == "deleted":
+        kw.update(deleted_frac=0.25, seed=906)
+    elif case == "two_divisions":
+        kw.update(T=8, D=2, seed=907)
+    sc = make_scene(oracle, **kw)
+    if scale != 1.0:
+        rng0 = sc["rng"]
+
+        class _Scaled:
+            def standard_normal(self, shape):
+                return rng0.standard_normal(shape) * scale
+        sc["rng"] = _Scaled()
+    sc["params"]["clustered"] = bool(kw.get("clustered"))
+    lim = min(256, kw["B"])
+    check_route(pkg, sc, nq=48, limits=(lim, 17))
+    if case == "tiny":                       # one and two partitions per table
+        for n in (40, 100):
+            sc = make_scene(oracle, **dict(kw, n=n, seed=910 + n))
+            check_route(pkg, sc, nq=16, limits=(64,))
+
+
 def test_zz_bounded_select_was_exercised():
     """The scenes above must have driven the bounded select itself, and its hand-back to the full select."""
     assert sum(1 for r in LAZY_RUNS if r["lazy"]) >= 10
