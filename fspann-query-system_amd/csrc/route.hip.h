@@ -280,7 +280,14 @@ __device__ __forceinline__ int route_probe_replay(const RouteTable& tb, const in
 // kP / kW (0 = run-time values): probes per table and code words as constants (the shape-specialised bounded select, route_lazy.hip.h).
 template <typename OutPtr, int kP = 0, int kW = 0>
 __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool act, const uint64_t* qc, const RouteTable tb, int G, int gl,
-                                                 int grp_in_wave, int32_t* w3, OutPtr po) {
+                                                 int grp_in_wave, int32_t* w3, OutPtr po, long long* pstamp = nullptr) {
+#ifdef FSPANN_DEBUG_STAMPS
+    int pst_i = 0;
+#define PROBE_STAMP() do { if (pstamp && pst_i < 12) pstamp[pst_i++] = wall_clock64(); } while (0)
+#else
+#define PROBE_STAMP() do { (void)pstamp; } while (0)
+#endif
+    PROBE_STAMP();
     const int W = kW > 0 ? kW : prm.W, P = kP > 0 ? kP : prm.P;
     const int nd = 2 * P - 1;
     act = act && tb.nparts > 0;
@@ -291,6 +298,9 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << gshift);
     // GreedyPartitioner.computeKey: code bit i -> key bit 62-i (i < 63)
     const int64_t qKey = act ? static_cast<int64_t>(__brevll(qc[0]) >> 1) : 0;
+#ifdef FSPANN_DEBUG_STAMPS
+    if (pstamp) { asm volatile("" :: "v"(static_cast<int>(qKey)), "v"(tb.nparts)); PROBE_STAMP(); }   // code word and table record are here
+#endif
     const int RW = kW > 0 ? ((3 + kW + 1) & ~1) : prm.rec_words;     // (= the host's rec_words for W code words)
     const int64_t* recs = prm.recs + tb.part_base * RW;     // this table's partition records
     // a = first partition with maxKey >= qKey ; e = first partition with minKey > qKey.
@@ -304,6 +314,8 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
         const int2 d0 = dd[0], d1 = dd[1];
         loA = d0.x; hiA = d1.x; loE = d0.y; hiE = d1.y;
     }
+    asm volatile("" :: "v"(loA), "v"(hiA));
+    PROBE_STAMP();     // 1: directory entry is here
     // G-ary search, both at once, from the directory's (or the whole table's) bounds.  (A variant that fetched key ranges, codes
     // and id ranges of a whole window of <= 32 partitions in one round and resolved everything from registers was measured and
     // dropped: the brackets are rarely that narrow — LSH keys are skewed — and its 14 extra registers per lane were the
@@ -334,6 +346,7 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
                 loE = nlo;
             }
         }
+        PROBE_STAMP();     // 2..: one per search round
     }
     int center = 0;
     if (act) {
@@ -375,7 +388,14 @@ __device__ __forceinline__ int route_probe_table(const RouteParams& prm, bool ac
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    return act ? route_probe_replay(tb, P, nd, center, gl, w3, po) : 0;
+    PROBE_STAMP();         // window written
+    const int np_ = act ? route_probe_replay(tb, P, nd, center, gl, w3, po) : 0;
+    PROBE_STAMP();         // replay done
+#ifdef FSPANN_DEBUG_STAMPS
+    if (pstamp) pstamp[15] = pst_i;
+#endif
+#undef PROBE_STAMP
+    return np_;
 }
 
 __global__ __launch_bounds__(kProbeThreads) void route_probe_kernel(RouteParams prm, int4* __restrict__ probe_out,

@@ -252,8 +252,15 @@ __device__ __forceinline__ void route_lazy_run(const RouteParams& prm, unsigned 
                 const bool act = td < TD;
                 const int tdc = act ? td : 0;
                 const int Wc = (kTD > 0) ? 1 : prm.W;
+#ifdef FSPANN_DEBUG_STAMPS
+                // FSPANN_PROBE_STAMPS build (tools/route_probe_stamps.py): the first lane group of the first query of a workgroup stamps the
+                // probe's rounds into the second half of the workgroup's debug row pair (dbg rows are 16 words; rows grid..2*grid-1)
+                long long* pst = (prm.dbg && tid == 0 && qi == block_id && t0 == 0) ? prm.dbg + (static_cast<long long>(gridDim.x) + block_id) * 16 : nullptr;
+#else
+                long long* pst = nullptr;
+#endif
                 const int np = route_probe_table<int4*, kP, (kTD > 0 ? 1 : 0)>(prm, act, prm.codes + (qi * TD + tdc) * Wc, prm.tables[tdc], G, gl, grp_in_wave,
-                                                                             w3, plist + tdc * P);
+                                                                             w3, plist + tdc * P, pst);
                 if (act && gl == 0) nprobe_l[td] = np;
             }
             __syncthreads();
