@@ -1163,7 +1163,69 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 const int SPt = (S + 63) >> 6, nwv = nthreads >> 6;
                 int capk = prm.cap0;
                 long long thrk = thr0;
-                for (int stage = 0; stage < 24; stage++) {
+                // A map that resized once or twice (the shipped profiles: 28 000 ids in a table that started at 32 768): ALL its
+                // capacity stages in ONE walk over the tuples, a counter table per stage side by side in LDS (cap0 / 8 + 2 cap0 / 8 +
+                // ... words) — a first occurrence of insertion rank r counts in every stage whose last rank is >= r.
+                bool fused_stages = false;
+                if (!single && SPt == 1) {
+                    int nst = 0;
+                    long long words = 0, thr_i = thr0;
+                    int cap_i = prm.cap0;
+                    while (nst < 3) {
+                        words += cap_i >> 3;
+                        nst++;
+                        if (thr_i >= static_cast<long long>(n) - 1) break;
+                        cap_i <<= 1; thr_i <<= 1;
+                    }
+                    if (thr_i >= static_cast<long long>(n) - 1 && words <= nib_words) {
+                        fused_stages = true;
+                        __syncthreads();
+                        for (int i = tid; i < static_cast<int>(words); i += nthreads) nib[i] = 0u;
+                        __syncthreads();
+                        const long long e0 = (thr0 < static_cast<long long>(n) - 1) ? thr0 : static_cast<long long>(n) - 1;
+                        const long long e1 = (2 * static_cast<long long>(thr0) < static_cast<long long>(n) - 1) ? 2 * static_cast<long long>(thr0) : static_cast<long long>(n) - 1;
+                        const int o1 = prm.cap0 >> 3, o2 = o1 + (prm.cap0 >> 2);
+                        bool hit = false;
+                        constexpr int kTU = 4;
+                        for (int ts0 = wave; ts0 < TP; ts0 += nwv * kTU) {      // wave-uniform: the ballots need every lane
+                            if (ts0 > cut) break;
+                            uint16_t vb[kTU];
+                            int32_t ib[kTU];
+#pragma unroll
+                            for (int u = 0; u < kTU; u++) {
+                                const int ts = ts0 + u * nwv;
+                                const bool in = ts < TP && ts <= cut && lane < S;
+                                vb[u] = in ? tscore[ts * S + lane] : static_cast<uint16_t>(0);
+                                ib[u] = in ? tup[ts * S + lane] : -1;
+                            }
+#pragma unroll
+                            for (int u = 0; u < kTU; u++) {
+                                const int ts = ts0 + u * nwv;
+                                if (ts >= TP || ts > cut) break;                 // wave-uniform
+                                const bool f = (vb[u] & kFirstFlag) != 0;
+                                const unsigned long long bm = __ballot(f);
+                                const long long rank = stepcnt[ts] + __popcll(bm & ((1ull << lane) - 1ull));
+                                if (!f) continue;
+                                const uint32_t sp = spread_of(ib[u]);
+                                if (rank <= e0) {
+                                    const uint32_t b = sp & static_cast<uint32_t>(prm.cap0 - 1), sh = (b & 7u) * 4u;
+                                    hit = hit || (((atomicAdd(&nib[b >> 3], 1u << sh) >> sh) & 15u) >= 8u);
+                                }
+                                if (nst >= 2 && rank <= e1) {
+                                    const uint32_t b = sp & static_cast<uint32_t>(2 * prm.cap0 - 1), sh = (b & 7u) * 4u;
+                                    hit = hit || (((atomicAdd(&nib[o1 + (b >> 3)], 1u << sh) >> sh) & 15u) >= 8u);
+                                }
+                                if (nst >= 3) {                                  // the last stage: every rank
+                                    const uint32_t b = sp & static_cast<uint32_t>(4 * prm.cap0 - 1), sh = (b & 7u) * 4u;
+                                    hit = hit || (((atomicAdd(&nib[o2 + (b >> 3)], 1u << sh) >> sh) & 15u) >= 8u);
+                                }
+                            }
+                        }
+                        if (hit) s_tree = 1;
+                        __syncthreads();
+                    }
+                }
+                for (int stage = 0; stage < 24 && !fused_stages; stage++) {
                     const long long endk = (thrk < static_cast<long long>(n) - 1) ? thrk : static_cast<long long>(n) - 1;   // last rank of this stage
                     __syncthreads();
                     for (int i = tid; i < (capk >> 3); i += nthreads) nib[i] = 0u;
