@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--shipped-steps", type=int, default=40, help="timed steps of each shipped-profile child run")
     ap.add_argument("--solo-tail", type=int, default=16, help="drained solo dispatches of the refinement scan timed AFTER the timed region "
                                                               "(the roofline's readings do not depend on --steps)")
+    ap.add_argument("--solo-in-region", action="store_true",
+                    help="also take drained solo readings INSIDE the timed region (every ~40th step drains all contexts and runs alone: rounds 2-3; "
+                         "costs the region about two steps per reading).  Default: the solo readings come from the untimed tail (--solo-tail), the "
+                         "timed region holds exactly --steps pipeline steps and only the overlapped readings")
     ap.add_argument("--launch-check", action="store_true", help="(tests) only prove the N-rank launch: every rank joins a gloo group, rank 0 prints one JSON line")
     args = ap.parse_args()
 
@@ -357,6 +361,7 @@ def main():
     use_front = [False]   # set by timed() for the region it times (the untimed passes use the plain three-launch step)
     active = [1]          # contexts the steps alternate between
     overlapped = [None]   # (dispatches, mean ms) of sampled refinement scans that ran next to other contexts' kernels
+    host_issue_s = [None] # seconds the host needed to ISSUE the launches of the last timed() region (before any synchronisation)
 
     def step(mode, events=None, batch=None, force_ctx=None):
         """One pass of the hot path over one batch.  mode: dense | store | gather.  events: 5 torch events recorded around
@@ -517,6 +522,7 @@ def main():
             step(mode)
         barrier()
         every = max(2, steps // max(1, min(8, steps // 40)))   # up to eight solo readings, at most one per 40 steps (a drain costs ~2 steps)
+        drain_in_region = args.solo_in_region or args.solo_tail <= 0 or shipped
         solo = []
         if with_events and nact == 1:
             ctxs[0].refine_timing_begin(steps, every)
@@ -525,7 +531,7 @@ def main():
                 c_.refine_timing_begin(steps, max(2, every // 2))
         t_s = time.perf_counter()
         for i in range(steps):
-            if with_events and nact > 1 and (i % every) == every - 1:
+            if with_events and nact > 1 and drain_in_region and (i % every) == every - 1:
                 for c_ in ctxs[:nact]:
                     c_.sync()
                 ctxs[0].refine_timing_begin(2, 1)        # solo reading: everything drained, this step runs alone on context 0
@@ -534,6 +540,7 @@ def main():
             else:
                 step(mode)
         flush(nact)
+        host_issue_s[0] = time.perf_counter() - t_s      # every launch of the region has been handed to the runtime by now
         for c_ in ctxs[:nact]:
             c_.sync()
         torch.cuda.synchronize()
@@ -606,6 +613,7 @@ def main():
         elapsed, rt, TIMED_EVERY = timed(mode, args.steps, args.warmup, nact=nctx, with_events=True, front=args.pipeline == "front")
         tick_fused = False
     overlapped_main = overlapped[0]
+    host_issue_main = host_issue_s[0]
     # ---------------- what was timed is what is checked: the LAST step each context ran inside the timed region (front_kernel +
     # the scan that finishes PENDING queries, on the clones' own streams) against the plain three-launch path on context 0 for the
     # same batch here, and against the CPU oracle in the cpu_baseline leg ------------------------------------------------------
@@ -1074,9 +1082,13 @@ def main():
                     working_set_bytes=(NB * Q * B * d * 4) if mode == "dense" else n * d * 4,
                     timing=("every %d-th step of the timed region runs its three stages as stand-alone kernels instead of the shared one; the "
                             "refinement-scan dispatch of those steps carries HIP start/stop events (hipExtLaunchKernel, on the context's stream)"
-                            if use_tick else ("every %d-th step of the timed region first drains all contexts and then runs alone; its refinement-scan "
-                                              "dispatch carries HIP start/stop events (hipExtLaunchKernel, on its context's stream): a SOLO duration, "
-                                              "measured inside the timed region") if nctx > 1 else
+                            if use_tick else (("every %d-th step of the timed region first drains all contexts and then runs alone; its refinement-scan "
+                                               "dispatch carries HIP start/stop events (hipExtLaunchKernel, on its context's stream): a SOLO duration, "
+                                               "measured inside the timed region") if (args.solo_in_region or args.solo_tail <= 0 or shipped) else
+                                              ("SOLO durations from the untimed tail behind the timed region (roofline.solo.tail: drained dispatches of the same "
+                                               "scan in the same pipeline, HIP start/stop events attached to each, hipExtLaunchKernel on the context's stream); "
+                                               "inside the timed region — which holds exactly --steps pipeline steps, no drain — every %d-th scan dispatch of the "
+                                               "other contexts carries events too: roofline.overlapped")) if nctx > 1 else
                             "HIP start/stop events attached to every %d-th refinement-scan dispatch of the timed region "
                             "(hipExtLaunchKernel, on the context's stream)") % TIMED_EVERY,
                     bracket_ms=round(float(st_mean[3]), 5),
@@ -1313,6 +1325,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "host_issue_ms_per_step": round(host_issue_main * 1000.0 / args.steps, 4) if host_issue_main else None,   # launch issue alone (Python + HIP runtime): if it is close to ms_per_step the region is host-bound
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
