@@ -49,7 +49,8 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
                ((static_cast<size_t>(pl.max_tuples) * 2 + 15) & ~size_t(15));
     };
     pl.small_bytes = small;
-    const size_t budget = static_cast<size_t>(c->lds_limit) - 1024;  // static __shared__ + margin
+    const size_t lds_cap = (c->knob_route_lds_kb > 0) ? std::min<size_t>(c->lds_limit, static_cast<size_t>(c->knob_route_lds_kb) * 1024) : static_cast<size_t>(c->lds_limit);
+    const size_t budget = lds_cap - 1024;  // static __shared__ + margin
     if (small + 8192 > budget) return fail(FSPANN_E_RANGE, "route: T*D*probes = %zu probe slots do not fit in LDS", TP);
     pl.arena_bytes = (arena(pl.sort_cap) + 255) & ~size_t(255);
     pl.lds_mode = (pl.arena_bytes + small <= budget) ? 1 : 0;
@@ -89,6 +90,7 @@ int plan_route(fspann_ctx* c, int probe_override, int64_t nq, int32_t limit, Rou
         // all resident workgroups inside the 256 MiB Infinity Cache (1024 workgroups x 470 KB at SIFT_P10_HIGH thrashed HBM)
         wgs_per_cu = (pl.arena_bytes * static_cast<size_t>(c->num_cus) * 2 <= (size_t(128) << 20)) ? std::min(wgs_per_cu, 2) : 1;
     }
+    if (c->knob_route_wgs > 0) wgs_per_cu = std::min(per_cu, c->knob_route_wgs);
     pl.grid = static_cast<int>(std::min<int64_t>(nq, static_cast<int64_t>(c->num_cus) * wgs_per_cu));
     pl.g_sort_stride = (pl.sort_cap < full_sort) ? full_sort : 0;
     // ---- bounded select: legal when the first `limit` entries do not depend on how many ids exist ----------------

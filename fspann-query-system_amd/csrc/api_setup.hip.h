@@ -293,6 +293,8 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_bincheck = env_int("FSPANN_ROUTE_BINCHECK", -1);
         c->knob_slice = env_int("FSPANN_ROUTE_SLICE", 1) != 0;
         c->knob_shape_spec = env_int("FSPANN_ROUTE_SHAPE_SPEC", 1) != 0;
+        c->knob_route_lds_kb = env_int("FSPANN_ROUTE_LDS_KB", 0);
+        c->knob_route_wgs = env_int("FSPANN_ROUTE_WGS", 0);
         c->knob_refine_run = env_int("FSPANN_REFINE_RUN", 1) != 0;
         c->knob_devflags = env_int("FSPANN_ROUTE_DEVFLAGS", 0);
         c->knob_dir_extra_bits = env_int("FSPANN_ROUTE_DIR_EXTRA_BITS", kDirBitsAuto);   // unset: as many as fit 64 MB (at most six)

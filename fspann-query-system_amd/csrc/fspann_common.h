@@ -103,6 +103,8 @@ struct fspann_ctx {
     int knob_tick_front = 100;       // FSPANN_TICK_FRONT: percent of a tick's Route workgroups that head the grid
     int knob_bincheck = -1;          // FSPANN_ROUTE_BINCHECK: the bounded select's exact treeify check (-1: on for opaque ids, off for decimal ordinals; 0 / 1 force)
     bool knob_shape_spec = true;     // FSPANN_ROUTE_SHAPE_SPEC=0: the bounded select's build with run-time tables x probes also for 16 x 5 (dev A/B)
+    int knob_route_lds_kb = 0;       // FSPANN_ROUTE_LDS_KB: LDS the full select may plan with (0 = all of it); less leaves room for scan workgroups beside it
+    int knob_route_wgs = 0;          // FSPANN_ROUTE_WGS: workgroups per CU of the full select's grid (0 = what fits, at most 4)
     int knob_devflags = 0;           // FSPANN_ROUTE_DEVFLAGS: dev A/B switches of the full select (route.hip.h)
     bool knob_refine_run = true;     // FSPANN_REFINE_RUN=0: long lists keep one partial top-k list per 256-row chunk (dev A/B)
     bool knob_slice = true;          // FSPANN_ROUTE_SLICE=0: the full select's global-arena mode builds its hash in the arena (dev A/B)
