@@ -186,7 +186,7 @@ __device__ __forceinline__ uint32_t decimal_string_hash_dev(uint32_t v) {
 }
 
 constexpr int kProbeThreads = 256;
-constexpr int kDupListMax = 512;
+constexpr int kDupListMax = 768;
 constexpr int kStageU = 12;                 // id loads in flight per lane while staging (one round trip for 10 tuples per lane)
 constexpr uint16_t kLiveFlag = 0x4000u;   // tscore: tuple slot holds a live (non-deleted) id
 
@@ -465,7 +465,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             ht = reinterpret_cast<uint32_t*>(sm + ((so + static_cast<size_t>(TD) * 4 + 15) & ~size_t(15)));
     }
 
-    __shared__ int s_n, s_raw, s_fill, s_cut, s_star, s_need, s_b1, s_lvl1, s_ndup, s_tree, s_suspect;
+    __shared__ int s_n, s_raw, s_fill, s_cut, s_star, s_need, s_b1, s_lvl1, s_ndup, s_tree, s_suspect, s_smin, s_lmax;
     __shared__ int s_slice[8];                  // sliced build: live tuples per slice of the id space
     // Sliced build (global-arena mode, long lists): the hash of ONE slice of the id space at a time, in the LDS region behind the
     // small arrays.  Random CAS / min on a 256 KB table in global memory were a third of the full select at SIFT_P10_HIGH
@@ -620,6 +620,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                       }
                     }
                     __syncthreads();
+                    if (sl == 0) FSP_STAMP(12);
                     // pass 2: every tuple of the slice looks its id up: the entry holds the FIRST tuple of the id; any other is a repeat
                     for (int j0 = tid; j0 < prm.max_tuples; j0 += nthreads * kSlU) {
                       int32_t idb[kSlU];
@@ -636,14 +637,18 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                         int f = j;
                         for (int tries = 0; tries < hs; tries++) {
                             const uint32_t cur = sht[slot];
-                            if (cur != kHtEmpty && (cur >> prm.seq_bits) == mytag && tup[cur & seq_mask] == id) { f = static_cast<int>(cur & seq_mask); break; }
+                            if (cur != kHtEmpty && (cur >> prm.seq_bits) == mytag) {
+                                const int cs = static_cast<int>(cur & seq_mask);
+                                if (cs == j) break;                              // the entry IS this tuple: a first occurrence — four of five
+                                if (tup[cs] == id) { f = cs; break; }            //   tuples end here, without the confirming read of the arena
+                            }
                             slot = (slot + stp) & hmask;
                         }
                         if (f != j) {
-                            const uint16_t v = tscore[j];
-                            tscore[j] = v & ~kFirstFlag;
-                            fseq[j] = f;
                             const int ts = FSP_TS(j);
+                            const uint16_t v = static_cast<uint16_t>(probe[ts].y) | kLiveFlag;     // what staging wrote, less the first flag: no read
+                            tscore[j] = v;
+                            fseq[j] = f;
                             atomicSub(&bins[v & 0x3FFF], 1);
                             atomicSub(&stepcnt[ts], 1);
                             atomicAdd(&dupcnt[ts / P], 1);
@@ -651,6 +656,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                       }
                     }
                     __syncthreads();
+                    if (sl == 0) FSP_STAMP(13);
                 }
             }
         }
@@ -728,18 +734,22 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
         // ---- B2: HARD_CAP — first probe step at which bestScore.size() reaches the cap ----------------
         int cut = 0x7FFFFFFF;
         if (prm.need_cap) {
-            if (tid == 0) {
-                int cum = 0, c = 0x7FFFFFFF;
-                for (int g = 0; g < TP; g++) {
-                    cum += stepcnt[g];
-                    if (cum >= prm.hard_cap) { c = g; break; }  // steps after g never run (PIS:657-659)
+            if (wave == 0) {      // running sum of the steps' new ids, 64 steps per trip (one thread adding them up: 16 us at 560 steps)
+                int carry = 0, c = 0x7FFFFFFF;
+                for (int g0 = 0; g0 < TP; g0 += 64) {        // wave-uniform trips
+                    const int g = g0 + lane;
+                    int incl = (g < TP) ? stepcnt[g] : 0;
+                    for (int off = 1; off < 64; off <<= 1) { const int u2 = __shfl_up(incl, off); if (lane >= off) incl += u2; }
+                    const unsigned long long hit = __ballot(g < TP && carry + incl >= prm.hard_cap);
+                    if (hit) { c = g0 + __ffsll(static_cast<long long>(hit)) - 1; break; }  // steps after c never run (PIS:657-659)
+                    carry += __shfl(incl, 63);
                 }
-                s_cut = c;
+                if (lane == 0) s_cut = c;
             }
             __syncthreads();
             cut = s_cut;
             if (cut != 0x7FFFFFFF) {  // entries and repeats behind the cut never existed
-                for (int j = tid; j < prm.max_tuples; j += nthreads) {
+                for (int j = (cut + 1) * S + tid; j < prm.max_tuples; j += nthreads) {      // (tuple j belongs to step j / S)
                     const uint16_t v = tscore[j];
                     if (!(v & kLiveFlag) || FSP_TS(j) <= cut) continue;
                     if (v & kFirstFlag) atomicSub(&bins[v & 0x3FFF], 1);
@@ -779,24 +789,51 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 if (improved) atomicAdd(&s_raw, improved);
                 __syncthreads();
             }
-        } else if (ndup > 0 && ndup <= kDupListMax) {
+        } else if (ndup > 0 && ndup <= kDupListMax && prm.nbins <= 256) {
             // all repeats in parallel: a repeat d improves iff its score is below the first occurrence's
             // and below every earlier repeat of the same id; the overall minimum (earliest on ties) is
             // the one that rewrites the entry's score.
-            for (int l = tid; l < ndup; l += nthreads) {
+            // The ids of the repeats are staged in LDS first — in bins[256 ...), free here (the score histogram uses bins[0, nbins)
+            // only; their scores join the tuple numbers in the list itself): each repeat walks ALL repeats looking for its id, and with the ids read from the tuple array
+            // in the arena that walk was a chain of L2 round trips (a few hundred repeats per query on data whose candidate lists
+            // overlap little, e.g. SIFT_P4_FAST on SIFT-like vectors: 97 us of a 300 us query).
+            // duplist[l] becomes (score << 23 | live << 22 | tuple number) — nothing reads the list afterwards
+            int32_t* dup_id = bins + 256;                                            // [kDupListMax]
+            static_assert(256 + kDupListMax <= 1024 && kSeqBits == 22, "the repeats' ids fit behind the score histogram; a tuple number is 22 bits");
+            const int nd8 = (ndup + 7) & ~7;                    // the walk below reads eight ids per trip: pad with an id no repeat has
+            for (int l = tid; l < nd8; l += nthreads) {
+                if (l >= ndup) { dup_id[l] = -1; continue; }
                 const int j = duplist[l];
-                if (!(tscore[j] & kLiveFlag)) continue;      // behind the HARD_CAP cut
-                const int32_t id = tup[j];
-                const int sc = probe[FSP_TS(j)].y;
+                dup_id[l] = tup[j];
+                duplist[l] = j | ((tscore[j] & kLiveFlag) ? (1 << 22) : 0) | (probe[FSP_TS(j)].y << 23);
+            }
+            __syncthreads();
+            for (int l = tid; l < ndup; l += nthreads) {
+                const int me = duplist[l];
+                if (!(me & (1 << 22))) continue;      // behind the HARD_CAP cut
+                const int j = me & static_cast<int>(kSeqMask);
+                const int32_t id = dup_id[l];
+                const int sc = static_cast<int>(static_cast<uint32_t>(me) >> 23);
                 const uint32_t f = ht[find_slot(id)] & seq_mask;
                 const int first_sc = probe[FSP_TS(static_cast<int>(f))].y;
                 bool improves = sc < first_sc, is_min = improves;
-                for (int l2 = 0; l2 < ndup && (improves || is_min); l2++) {
-                    const int j2 = duplist[l2];
-                    if (j2 == j || tup[j2] != id || !(tscore[j2] & kLiveFlag)) continue;
-                    const int sc2 = probe[FSP_TS(j2)].y;
-                    if (j2 < j && sc2 <= sc) improves = false;
-                    if (sc2 < sc || (sc2 == sc && j2 < j)) is_min = false;
+                // (eight ids per trip, four 8-byte LDS reads issued together — the array is only 8-byte aligned; a match is rare:
+                // an id has at most one repeat per table)
+                const int2* d2 = reinterpret_cast<const int2*>(dup_id);
+                for (int l0 = 0; l0 < nd8 && (improves || is_min); l0 += 8) {
+                    const int2 a0 = d2[l0 / 2], a1 = d2[l0 / 2 + 1], a2 = d2[l0 / 2 + 2], a3 = d2[l0 / 2 + 3];
+                    const int32_t i8[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int l2 = l0 + u;
+                        if (i8[u] != id || l2 == l) continue;
+                        const int o2 = duplist[l2];
+                        if (!(o2 & (1 << 22))) continue;
+                        const int j2 = o2 & static_cast<int>(kSeqMask);
+                        const int sc2 = static_cast<int>(static_cast<uint32_t>(o2) >> 23);
+                        if (j2 < j && sc2 <= sc) improves = false;
+                        if (sc2 < sc || (sc2 == sc && j2 < j)) is_min = false;
+                    }
                 }
                 if (improves) atomicAdd(&s_raw, 1);
                 if (is_min) {  // unique writer per id
@@ -806,7 +843,9 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 }
             }
             __syncthreads();
-        } else if (ndup > kDupListMax) {
+            for (int l = tid; l < nd8; l += nthreads) dup_id[l] = 0;   // bins[256 ...) back to zeros
+            __syncthreads();
+        } else if (ndup > 0) {
             for (int td = 0; td < TD; td++) {   // table phases: an id occurs at most once per table
                 if (dupcnt[td] == 0) continue;  // uniform
                 int improved = 0;
@@ -848,6 +887,15 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 star = wave_find_cut(bins, prm.nbins, prm.limit, lane, &before);
                 need = prm.limit - before;
                 tie = bins[star];
+            }
+            {   // lowest occupied level and the largest level up to the cut: the long-list ordering sizes its groups by them
+                int lo = 0x7FFFFFFF, big = 0;
+                for (int b = lane; b <= star; b += 64) {
+                    const int cb = bins[b];
+                    if (cb > 0) { lo = min(lo, b); big = max(big, cb); }
+                }
+                for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); big = max(big, __shfl_xor(big, off)); }
+                if (lane == 0) { s_smin = (lo == 0x7FFFFFFF) ? star : lo; s_lmax = big; }
             }
             if (lane == 0) {
                 s_star = star;   // entries with score < star are all selected; `need` more come from score == star
@@ -976,9 +1024,15 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             // the full select at SIFT_P4_FAST and 68 % at SIFT_P10_HIGH, tools/route_full_stamps.py.)
             uint32_t* gsort = kLds ? ht : reinterpret_cast<uint32_t*>(sm + ((so + static_cast<size_t>(TD) * 4 + 15) & ~size_t(15)));
             const int gcap_all = kLds ? prm.ht_size : prm.lds_sort_words;
+            // Groups = (score level, top gb bits of the bin).  Only the levels smin .. star can hold a selected entry, and the LARGEST of
+            // them decides how finely the bins must be cut for a group to fit a wave's slice: gb = enough bits to bring that level
+            // down to ~128 entries per group (ids spread evenly over the bins), as far as 1 024 groups allow.  (With a fixed four or
+            // five bits over all `bits + 1` levels, data whose scores crowd on two or three levels — SIFT-like vectors — filled groups
+            // beyond a wave's slice, and those are sorted by the whole workgroup one after the other: up to 240 us of a query.)
+            const int smin = min(s_smin, star), nlev = star - smin + 1;
             int gb = 0;                                      // top bits of the bin that join the score in the group number
-            while (gb < 5 && gb < capbits && (prm.nbins << (gb + 1)) <= 1024) gb++;
-            const int ngrp = prm.nbins << gb;
+            while (gb < 10 && gb < capbits && (nlev << (gb + 1)) <= 1024 && (s_lmax >> gb) > 128) gb++;
+            const int ngrp = nlev << gb;
             int32_t* cursor = reinterpret_cast<int32_t*>(gsort) + (gcap_all - 1024);      // [ngrp <= 1024] running output position per group
             const int nwv = nthreads >> 6;
             // LDS region: [per-wave slices: nwv * wcap][the sub-keys, when they fit][cursors: 1024].  With the sub-keys in LDS a group
@@ -997,7 +1051,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             auto group_of = [&](uint64_t key) -> int {
                 const int sc = static_cast<int>(key >> (kBucketBits + kSeqBits));
                 const uint32_t bucket = (static_cast<uint32_t>(key >> kSeqBits) & ((1u << kBucketBits) - 1u)) >> bshift;
-                return (sc << gb) | static_cast<int>(bucket >> (capbits - gb));
+                return ((sc - smin) << gb) | static_cast<int>(bucket >> (capbits - gb));
             };
             for (int i = tid; i < nsel; i += nthreads) atomicAdd(&bins[group_of(key_at(i))], 1);
             __syncthreads();
@@ -1046,7 +1100,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 for (int i = lane; i < c4; i += 64) slice[i] = (i < c) ? gsub[g0 + i] : 0xFFFFFFFFu;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const int scg = g >> gb;
+                const int scg = (g >> gb) + smin;
                 const uint4* s4 = reinterpret_cast<const uint4*>(slice);
                 for (int i = lane; i < c; i += 64) {
                     const uint32_t my = slice[i];
@@ -1079,7 +1133,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                     for (int i = tid; i < n2; i += nthreads) gsort[i] = (i < c) ? gsub[g0 + i] : 0xFFFFFFFFu;
                     __syncthreads();
                     bitonic_sort_u32(gsort, n2, tid, nthreads);
-                    const int scg = g >> gb;
+                    const int scg = (g >> gb) + smin;
                     for (int i = tid; i < c; i += nthreads) {
                         const int rank = g0 + i;
                         if (rank < nout) {

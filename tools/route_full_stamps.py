@@ -23,9 +23,16 @@ prof = sys.argv[1] if len(sys.argv) > 1 else "P10"
 T, D, m, P, B, HC = dict(P10=(7, 8, 26, 10, 22000, 28000), P4=(5, 8, 20, 4, 8000, 10000), P6=(6, 8, 24, 6, 16000, 20000))[prof]
 n, d, Q = 1_000_000, 128, 1024
 rng = np.random.default_rng(1)
-Cc = rng.standard_normal((4096, d), dtype=np.float32)
-X = Cc[rng.integers(0, 4096, n)] + np.float32(0.15) * rng.standard_normal((n, d), dtype=np.float32)
-Qh = Cc[rng.integers(0, 4096, Q)] + np.float32(0.15) * rng.standard_normal((Q, d), dtype=np.float32)
+if os.environ.get("DATA", "").startswith("siftlike"):          # the bench's SIFT-like generator (shipped-profile children)
+    import importlib.util
+    _sp = importlib.util.spec_from_file_location("fspann_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    _b = importlib.util.module_from_spec(_sp); _sp.loader.exec_module(_b)
+    X, _Q, _ = _b.make_data(os.environ["DATA"], n, d, 1, Q, 13, 0)
+    Qh = np.ascontiguousarray(_Q[0])
+else:
+    Cc = rng.standard_normal((4096, d), dtype=np.float32)
+    X = Cc[rng.integers(0, 4096, n)] + np.float32(0.15) * rng.standard_normal((n, d), dtype=np.float32)
+    Qh = Cc[rng.integers(0, 4096, Q)] + np.float32(0.15) * rng.standard_normal((Q, d), dtype=np.float32)
 cfg = pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=2, dim=d, refinement_limit=B, max_global_candidates=HC, probe_override=P)
 ctx = pkg.FspannContext(cfg, 0)
 ctx.registry_initialize(X[:1000].astype(np.float64))
@@ -58,9 +65,9 @@ L.fspann_debug_route_stamps(ctx.handle, None)
 a = dbg.cpu().numpy().astype(np.float64)
 a = a[a[:, 0] > 0]
 TICK = 0.01
-names = {0: "start", 1: "reset + probe list", 8: "ids staged", 2: "hash built", 9: "repeats dropped, cap", 3: "repeat scores", 11: "level cuts", 4: "compacted",
+names = {0: "start", 1: "reset + probe list", 8: "ids staged", 12: "slice 0: table built", 13: "slice 0: repeats marked", 2: "hash built", 9: "repeats dropped, cap", 3: "repeat scores", 11: "level cuts", 4: "compacted",
          5: "ordered + written", 6: "treeify check, done"}
-order = [0, 1, 8, 2, 9, 3, 11, 4, 5, 6]
+order = [0, 1, 8, 12, 13, 2, 9, 3, 11, 4, 5, 6]
 print("workgroups with stamps:", len(a))
 prev = 0
 for s in order[1:]:
