@@ -1031,8 +1031,12 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             // beyond a wave's slice, and those are sorted by the whole workgroup one after the other: up to 240 us of a query.)
             const int smin = min(s_smin, star), nlev = star - smin + 1;
             int gb = 0;                                      // top bits of the bin that join the score in the group number
+            // (~128 per group: with 64 the sort gains a tenth, with 32 the per-group overhead takes it back — tools/route_full_stamps.py)
             while (gb < 10 && gb < capbits && (nlev << (gb + 1)) <= 1024 && (s_lmax >> gb) > 128) gb++;
             const int ngrp = nlev << gb;
+#ifdef FSPANN_DEBUG_STAMPS
+            if (tid == 0 && prm.dbg && qi == block_id) prm.dbg[block_id * 16 + 15] = nsel + (static_cast<long long>(ngrp) << 20) + (static_cast<long long>(nlev) << 32) + (static_cast<long long>(s_lmax) << 40);
+#endif
             int32_t* cursor = reinterpret_cast<int32_t*>(gsort) + (gcap_all - 1024);      // [ngrp <= 1024] running output position per group
             const int nwv = nthreads >> 6;
             // LDS region: [per-wave slices: nwv * wcap][the sub-keys, when they fit][cursors: 1024].  With the sub-keys in LDS a group
@@ -1067,6 +1071,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 }
             }
             __syncthreads();
+            FSP_STAMP(7);
             for (int i = tid; i < nsel; i += nthreads) {     // scatter: group by group (any order inside a group: it is sorted next)
                 const uint64_t key = key_at(i);
                 const uint32_t bucket = (static_cast<uint32_t>(key >> kSeqBits) & ((1u << kBucketBits) - 1u)) >> bshift;
@@ -1075,6 +1080,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             }
             __threadfence_block();
             __syncthreads();                                 // cursor[g] is now the END of group g; its start = end - bins[g]
+            FSP_STAMP(10);
             const uint32_t seqm = (1u << prm.seq_bits) - 1u;
             uint32_t* slice = gsort + static_cast<size_t>(wave) * wcap;
             // Every wave on its own: wave w takes the groups w, w + waves, ... (ascending, so it may stop at the first one behind the
@@ -1120,6 +1126,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             }
             if (any_big && lane == 0) s_cut = 1;
             __syncthreads();
+            FSP_STAMP(14);
             bool too_big = false;
             if (s_cut) {                                     // groups beyond a wave's slice: the whole workgroup sorts them one by one
                 for (int g = 0; g < ngrp; g++) {             // block-uniform

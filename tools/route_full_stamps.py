@@ -65,9 +65,9 @@ L.fspann_debug_route_stamps(ctx.handle, None)
 a = dbg.cpu().numpy().astype(np.float64)
 a = a[a[:, 0] > 0]
 TICK = 0.01
-names = {0: "start", 1: "reset + probe list", 8: "ids staged", 12: "slice 0: table built", 13: "slice 0: repeats marked", 2: "hash built", 9: "repeats dropped, cap", 3: "repeat scores", 11: "level cuts", 4: "compacted",
+names = {0: "start", 1: "reset + probe list", 8: "ids staged", 12: "slice 0: table built", 13: "slice 0: repeats marked", 2: "hash built", 9: "repeats dropped, cap", 3: "repeat scores", 11: "level cuts", 4: "compacted", 7: "groups counted", 10: "sub-keys scattered", 14: "groups sorted by waves",
          5: "ordered + written", 6: "treeify check, done"}
-order = [0, 1, 8, 12, 13, 2, 9, 3, 11, 4, 5, 6]
+order = [0, 1, 8, 12, 13, 2, 9, 3, 11, 4, 7, 10, 14, 5, 6]
 print("workgroups with stamps:", len(a))
 prev = 0
 for s in order[1:]:
@@ -77,4 +77,6 @@ for s in order[1:]:
         print("%-24s <- %-22s n=%4d  med %8.1f  p90 %8.1f  max %8.1f us" % (names[s], names[prev], ok.sum(), np.median(dt), np.percentile(dt, 90), dt.max()))
         prev = s
 tot = (a[:, 6] - a[:, 0]) * TICK
-print("first query of a workgroup, total us: med %.1f p90 %.1f max %.1f; nsel med %d" % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(a[:, 15])))
+v15 = a[:, 15].astype(np.int64)
+print("first query of a workgroup, total us: med %.1f p90 %.1f max %.1f; nsel med %d; groups med %d, levels med %d, largest level med %d" %
+      (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(v15 & 0xFFFFF), np.median((v15 >> 20) & 0xFFF), np.median((v15 >> 32) & 0xFF), np.median(v15 >> 40)))
