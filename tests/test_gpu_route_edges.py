@@ -115,6 +115,18 @@ def test_heavy_repeats_same_gfunction(pkg, oracle):
     assert np.array_equal(count, raw)  # repeats never improve
 
 
+def test_repeat_list_capacity_boundary(pkg, oracle):
+    # 12 tables x 5 probes x 64 = 3 840 tuples over 11-20 k ids: 500-1 000 repeats per query, on both sides of the repeat list's capacity
+    # (kDupListMax = 768: the list walked in LDS below it, table by table above it) — rawSeen counts every strict improvement either way
+    seen = []
+    for n, seed in ((11000, 61), (13000, 62), (15000, 63), (17000, 64), (20000, 65)):
+        sc = make_scene(oracle, n=n, d=12, T=4, D=3, m=10, lam=2, B=512, seed=seed)
+        count, raw = check_route(pkg, sc, nq=24, limits=(None, 512))
+        seen += list(3840 - count)
+    seen = np.array(seen)
+    assert (seen <= 768).sum() >= 8 and (seen > 768).sum() >= 8, (seen.min(), seen.max())
+
+
 def test_tiny_tables(pkg, oracle):
     for n in (1, 5, 64, 65, 130):
         sc = make_scene(oracle, n=n, d=4, T=2, D=2, m=4, lam=2, B=33, seed=20 + n)

@@ -28,15 +28,30 @@ def clustered(rng, n, d, nc=1024, sigma=0.15):
     return C, (C[rng.integers(0, nc, n)] + np.float32(sigma) * rng.standard_normal((n, d), dtype=np.float32))
 
 
+def siftlike(rng, n, d, r=16, noise=6.0):
+    """bench.py's SIFT-like generator (integers 0..255 of intrinsic dimension r): candidate lists that overlap little — a few hundred
+    repeats per query instead of thousands, scores crowded on a few levels: other paths of the full select than the blobs take."""
+    U = (rng.standard_normal((r, d)) / np.sqrt(r)).astype(np.float32)
+    def draw(cnt):
+        y = rng.standard_normal((cnt, r), dtype=np.float32) @ U
+        return np.clip(np.rint(np.float32(64.0) + np.float32(48.0) * y + np.float32(noise) * rng.standard_normal((cnt, d), dtype=np.float32)), 0, 255).astype(np.float32)
+    return draw
+
+
+@pytest.mark.parametrize("data", ["clustered", "siftlike"])
 @pytest.mark.parametrize("name", sorted(PROFILES))
-def test_shipped_profile_against_the_oracle(pkg, oracle, name):
+def test_shipped_profile_against_the_oracle(pkg, oracle, name, data):
     import torch
     pr = PROFILES[name]
     n, d, nq = 200_000, 128, 48
     T, D, m, lam, P, B, HC = (pr[k] for k in ("T", "D", "m", "lam", "probes", "B", "hard_cap"))
     rng = np.random.default_rng(11)
-    C, X = clustered(rng, n, d)
-    Q = (C[rng.integers(0, len(C), nq)] + np.float32(0.15) * rng.standard_normal((nq, d), dtype=np.float32))
+    if data == "clustered":
+        C, X = clustered(rng, n, d)
+        Q = (C[rng.integers(0, len(C), nq)] + np.float32(0.15) * rng.standard_normal((nq, d), dtype=np.float32))
+    else:
+        draw = siftlike(rng, n, d)
+        X, Q = draw(n), draw(nq)
     X64 = X.astype(np.float64)
     alpha, r, w = oracle.registry_init(X64[:1000], m, 13, T, D)
     o = oracle.Oracle(T, D, m, lam, d, max_global_candidates=HC, refinement_limit=B, probe_override=P)
