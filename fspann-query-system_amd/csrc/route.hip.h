@@ -789,46 +789,82 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 if (improved) atomicAdd(&s_raw, improved);
                 __syncthreads();
             }
-        } else if (ndup > 0 && ndup <= kDupListMax && prm.nbins <= 256) {
-            // all repeats in parallel: a repeat d improves iff its score is below the first occurrence's
-            // and below every earlier repeat of the same id; the overall minimum (earliest on ties) is
-            // the one that rewrites the entry's score.
-            // The ids of the repeats are staged in LDS first — in bins[256 ...), free here (the score histogram uses bins[0, nbins)
-            // only; their scores join the tuple numbers in the list itself): each repeat walks ALL repeats looking for its id, and with the ids read from the tuple array
-            // in the arena that walk was a chain of L2 round trips (a few hundred repeats per query on data whose candidate lists
-            // overlap little, e.g. SIFT_P4_FAST on SIFT-like vectors: 97 us of a 300 us query).
-            // duplist[l] becomes (score << 23 | live << 22 | tuple number) — nothing reads the list afterwards
-            int32_t* dup_id = bins + 256;                                            // [kDupListMax]
-            static_assert(256 + kDupListMax <= 1024 && kSeqBits == 22, "the repeats' ids fit behind the score histogram; a tuple number is 22 bits");
-            const int nd8 = (ndup + 7) & ~7;                    // the walk below reads eight ids per trip: pad with an id no repeat has
-            for (int l = tid; l < nd8; l += nthreads) {
-                if (l >= ndup) { dup_id[l] = -1; continue; }
-                const int j = duplist[l];
-                dup_id[l] = tup[j];
-                duplist[l] = j | ((tscore[j] & kLiveFlag) ? (1 << 22) : 0) | (probe[FSP_TS(j)].y << 23);
+        } else if (ndup > 0 && ndup <= kDupListMax && prm.nbins <= 256 && prm.ht_size <= 65536) {
+            // All repeats in parallel: a repeat improves iff its score is below the first occurrence's and below every earlier
+            // repeat of the same id; the overall minimum (earliest on ties) is the one that rewrites the entry's score.
+            // "The same id" = "the same hash slot", and the slot doubles as a counter: once every repeat has found its slot, each
+            // live one adds 1 to the slot's TAG field (nothing reads the table after this step), so (tag now - tag of the id) is the
+            // number of live repeats of that id.  A lone repeat — most of them — is settled on the spot; the others (a few dozen
+            // to a few hundred) are listed and walk only that list.  (Every repeat walking all of them, ids read from the arena:
+            // 97 us of a 300 us query at SIFT_P4_FAST on SIFT-like data; with the ids in LDS: 28 us; this: see DESIGN.md.)
+            // Scratch in bins[256 ...), free here (the score histogram uses bins[0, nbins) only): the list of those with company
+            // (slot | index).  duplist[l] becomes (score << 23 | live << 22 | tuple number).
+            uint32_t* mlist = reinterpret_cast<uint32_t*>(bins + 256);                           // [kDupListMax] slot << 16 | index in duplist
+            static_assert(256 + kDupListMax <= 1024 && kDupListMax % 8 == 0 && kDupListMax <= 65536 && kSeqBits == 22, "scratch behind the score histogram; a tuple number is 22 bits");
+            constexpr int kDupTrips = (kDupListMax + kThreads - 1) / kThreads;
+            uint32_t my_slot[kDupTrips], my_f[kDupTrips], my_tag[kDupTrips];
+            if (tid == 0) s_fill = 0;                                  // (s_fill: free until the compaction; reset below)
+#pragma unroll
+            for (int t = 0; t < kDupTrips; t++) {
+                const int l = tid + t * kThreads;
+                my_slot[t] = 0; my_f[t] = 0; my_tag[t] = 0;
+                if (l < ndup) {
+                    const int j = duplist[l];
+                    const int32_t id = tup[j];
+                    const bool live = (tscore[j] & kLiveFlag) != 0;
+                    duplist[l] = j | (live ? (1 << 22) : 0) | (probe[FSP_TS(j)].y << 23);
+                    const uint32_t sl = find_slot(id);
+                    my_slot[t] = sl;
+                    my_f[t] = ht[sl] & seq_mask;
+                    my_tag[t] = id_tag(id);
+                }
+            }
+            __syncthreads();                                           // every repeat has its slot: the table's tags may go
+#pragma unroll
+            for (int t = 0; t < kDupTrips; t++) {
+                const int l = tid + t * kThreads;
+                if (l < ndup && (duplist[l] & (1 << 22))) atomicAdd(&ht[my_slot[t]], 1u << prm.seq_bits);
             }
             __syncthreads();
-            for (int l = tid; l < ndup; l += nthreads) {
+#pragma unroll
+            for (int t = 0; t < kDupTrips; t++) {
+                const int l = tid + t * kThreads;
+                if (l >= ndup) continue;
                 const int me = duplist[l];
-                if (!(me & (1 << 22))) continue;      // behind the HARD_CAP cut
-                const int j = me & static_cast<int>(kSeqMask);
-                const int32_t id = dup_id[l];
+                if (!(me & (1 << 22))) continue;                       // behind the HARD_CAP cut
+                const uint32_t company = ((ht[my_slot[t]] >> prm.seq_bits) - my_tag[t]) & (0xFFFFFFFFu >> prm.seq_bits);
+                if (company > 1u) { mlist[atomicAdd(&s_fill, 1)] = (my_slot[t] << 16) | static_cast<uint32_t>(l); continue; }
                 const int sc = static_cast<int>(static_cast<uint32_t>(me) >> 23);
-                const uint32_t f = ht[find_slot(id)] & seq_mask;
+                const int first_sc = probe[FSP_TS(static_cast<int>(my_f[t]))].y;
+                if (sc < first_sc) {                                   // the id's only repeat: it improves, and it is the minimum
+                    atomicAdd(&s_raw, 1);
+                    tscore[my_f[t]] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
+                    atomicSub(&bins[first_sc], 1);
+                    atomicAdd(&bins[sc], 1);
+                }
+            }
+            __syncthreads();
+            const int nmulti = s_fill;
+            const uint2* m2p = reinterpret_cast<const uint2*>(mlist);       // (8-byte aligned: bins is)
+            for (int mi = tid; mi < nmulti; mi += nthreads) {
+                const uint32_t mine = mlist[mi];
+                const int l = static_cast<int>(mine & 0xFFFFu);
+                const uint32_t sl = mine >> 16;
+                const int me = duplist[l];
+                const int j = me & static_cast<int>(kSeqMask);
+                const int sc = static_cast<int>(static_cast<uint32_t>(me) >> 23);
+                const uint32_t f = ht[sl] & seq_mask;                   // (the adds went to the tag field)
                 const int first_sc = probe[FSP_TS(static_cast<int>(f))].y;
                 bool improves = sc < first_sc, is_min = improves;
-                // (eight ids per trip, four 8-byte LDS reads issued together — the array is only 8-byte aligned; a match is rare:
-                // an id has at most one repeat per table)
-                const int2* d2 = reinterpret_cast<const int2*>(dup_id);
-                for (int l0 = 0; l0 < nd8 && (improves || is_min); l0 += 8) {
-                    const int2 a0 = d2[l0 / 2], a1 = d2[l0 / 2 + 1], a2 = d2[l0 / 2 + 2], a3 = d2[l0 / 2 + 3];
-                    const int32_t i8[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
+                // eight list entries per trip (four 8-byte LDS reads issued together; entries past the end are stale and are ruled out
+                // by their position)
+                for (int m0 = 0; m0 < nmulti && (improves || is_min); m0 += 8) {
+                    const uint2 a0 = m2p[m0 / 2], a1 = m2p[m0 / 2 + 1], a2 = m2p[m0 / 2 + 2], a3 = m2p[m0 / 2 + 3];
+                    const uint32_t e8[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        const int l2 = l0 + u;
-                        if (i8[u] != id || l2 == l) continue;
-                        const int o2 = duplist[l2];
-                        if (!(o2 & (1 << 22))) continue;
+                        if ((e8[u] >> 16) != sl || m0 + u >= nmulti || m0 + u == mi) continue;
+                        const int o2 = duplist[e8[u] & 0xFFFFu];
                         const int j2 = o2 & static_cast<int>(kSeqMask);
                         const int sc2 = static_cast<int>(static_cast<uint32_t>(o2) >> 23);
                         if (j2 < j && sc2 <= sc) improves = false;
@@ -843,7 +879,8 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 }
             }
             __syncthreads();
-            for (int l = tid; l < nd8; l += nthreads) dup_id[l] = 0;   // bins[256 ...) back to zeros
+            for (int l = tid; l < kDupListMax; l += nthreads) bins[256 + l] = 0;   // bins[256 ...) back to zeros
+            if (tid == 0) s_fill = 0;
             __syncthreads();
         } else if (ndup > 0) {
             for (int td = 0; td < TD; td++) {   // table phases: an id occurs at most once per table

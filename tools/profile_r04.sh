@@ -17,10 +17,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # 4) the reference's shipped profiles, one context, one stream: solo durations of the full select and the run-of-chunks scan
 for w in sift1m_P4_FAST sift1m_P10_HIGH; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$w -- python3 $B --workload $w --k 100 --data clustered --pipeline serial --steps 20 --warmup 3 > $O/$w.json 2> $O/$w.log
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$w -- python3 $B --workload $w --k 100 --data ${SHIPPED_DATA:-siftlike:16:6} --pipeline serial --steps 20 --warmup 3 > $O/$w.json 2> $O/$w.log
   echo "$w done"
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${w}_pmc_$c -- python3 $B --workload $w --k 100 --data clustered --pipeline serial --steps 6 --warmup 2 > $O/${w}_pmc_$c.json 2> $O/${w}_pmc_$c.log
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${w}_pmc_$c -- python3 $B --workload $w --k 100 --data ${SHIPPED_DATA:-siftlike:16:6} --pipeline serial --steps 6 --warmup 2 > $O/${w}_pmc_$c.json 2> $O/${w}_pmc_$c.log
   done
   echo "$w pmc done"
 done

@@ -65,7 +65,7 @@ L.fspann_debug_route_stamps(ctx.handle, None)
 a = dbg.cpu().numpy().astype(np.float64)
 a = a[a[:, 0] > 0]
 TICK = 0.01
-names = {0: "start", 1: "reset + probe list", 8: "ids staged", 12: "slice 0: table built", 13: "slice 0: repeats marked", 2: "hash built", 9: "repeats dropped, cap", 3: "repeat scores", 11: "level cuts", 4: "compacted", 7: "groups counted", 10: "sub-keys scattered", 14: "groups sorted by waves",
+names = {0: "start", 1: "reset + probe list", 8: "ids staged", 12: "slice 0: table built / repeats staged", 13: "slice 0: repeats marked / repeats walked", 2: "hash built", 9: "repeats dropped, cap", 3: "repeat scores", 11: "level cuts", 4: "compacted", 7: "groups counted", 10: "sub-keys scattered", 14: "groups sorted by waves",
          5: "ordered + written", 6: "treeify check, done"}
 order = [0, 1, 8, 12, 13, 2, 9, 3, 11, 4, 7, 10, 14, 5, 6]
 print("workgroups with stamps:", len(a))
