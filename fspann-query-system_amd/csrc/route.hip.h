@@ -768,7 +768,82 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
         FSP_STAMP(9);
 
         // ---- B3: repeated occurrences: min score + strict improvements in table order (PIS:744-750) --
-        if (sliced) {
+        bool b3_done = false;
+        if (sliced && !prm.out_raw) {
+            // Nobody asked for rawSeen (the search path never does: it is a profiler counter of the reference, PIS:744-750), so all
+            // that is needed is every id's LOWEST score — no order among its repeats, no table phases: the live repeats are listed
+            // once (LDS region, free between the hash build and the ordering: (score | tuple, first occurrence) per repeat), every
+            // one takes a 32-bit minimum on its first occurrence's word of fseq (unused for a first occurrence), and the repeat that
+            // finds ITS OWN (score | tuple) there afterwards is the id's unique lowest: it rewrites the entry if it improves it.
+            // SIFT_P10_HIGH: 56 table phases of three dependent arena reads each were 60 us of a 450 us query.
+            if (wave == 0) {
+                int c = 0;
+                for (int td = lane; td < TD; td += 64) c += dupcnt[td];
+                for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+                if (lane == 0) { s_b1 = c; s_fill = 0; }        // (s_b1, s_fill: free until the level cuts / the compaction)
+            }
+            __syncthreads();
+            const int nrep = s_b1;
+            if (2 * static_cast<int64_t>(nrep) <= prm.lds_sort_words) {      // uniform
+                uint32_t* rl = lds_region;
+                constexpr int kRlU = 8;
+                for (int jb = 0; jb < prm.max_tuples; jb += nthreads * kRlU) {     // uniform trips: the ballots need every lane
+                    uint16_t vb[kRlU];
+                    int32_t fb[kRlU];
+#pragma unroll
+                    for (int u = 0; u < kRlU; u++) { const int j = jb + u * nthreads + tid; vb[u] = (j < prm.max_tuples) ? tscore[j] : static_cast<uint16_t>(0); }
+#pragma unroll
+                    for (int u = 0; u < kRlU; u++) {
+                        const int j = jb + u * nthreads + tid;
+                        const bool rep = (vb[u] & kLiveFlag) && !(vb[u] & kFirstFlag);
+                        fb[u] = rep ? fseq[j] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kRlU; u++) {
+                        const int j = jb + u * nthreads + tid;
+                        const bool rep = fb[u] >= 0;
+                        const unsigned long long bm = __ballot(rep);
+                        int basepos = 0;
+                        if (bm) {
+                            if (lane == 0) basepos = atomicAdd(&s_fill, __popcll(bm));
+                            basepos = __shfl(basepos, 0);
+                        }
+                        if (rep) {
+                            const int pos = basepos + __popcll(bm & ((1ull << lane) - 1ull));
+                            rl[2 * pos] = (static_cast<uint32_t>(vb[u] & 0x3FFFu) << 22) | static_cast<uint32_t>(j);
+                            rl[2 * pos + 1] = static_cast<uint32_t>(fb[u]);
+                            fseq[fb[u]] = -1;                     // = 0xFFFFFFFF: above every (score | tuple)
+                        }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+                const int nr = s_fill;
+                for (int i = tid; i < nr; i += nthreads) atomicMin(reinterpret_cast<uint32_t*>(fseq) + rl[2 * i + 1], rl[2 * i]);
+                __threadfence_block();
+                __syncthreads();
+                for (int i = tid; i < nr; i += nthreads) {
+                    const uint32_t mine = rl[2 * i];
+                    const int f = static_cast<int>(rl[2 * i + 1]);
+                    // (an atomic load: the minimum was taken in L2, a plain load may be served by this CU's L1 copy of the -1 stored above)
+                    const uint32_t low = __hip_atomic_load(reinterpret_cast<uint32_t*>(fseq) + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (low != mine) continue;
+                    const int sc = static_cast<int>(mine >> 22);
+                    const int first_sc = probe[FSP_TS(f)].y;
+                    if (sc < first_sc) {
+                        tscore[f] = static_cast<uint16_t>(sc) | kFirstFlag | kLiveFlag;
+                        atomicSub(&bins[first_sc], 1);
+                        atomicAdd(&bins[sc], 1);
+                    }
+                }
+                __syncthreads();
+                b3_done = true;
+            }
+            if (tid == 0) { s_fill = 0; s_b1 = 0; }
+            __syncthreads();
+        }
+        if (b3_done) {
+        } else if (sliced) {
             for (int td = 0; td < TD; td++) {   // table phases (an id occurs at most once per table); the first occurrence comes from fseq
                 if (dupcnt[td] == 0) continue;  // uniform
                 int improved = 0;
