@@ -487,6 +487,13 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
 
     // hash entries are (tag(id) << seq_bits) | seq: a failed CAS can tell "other id" from the returned word alone;
     // tup[] is consulted only when the tags agree (true repeats, or a 2^-(32-seq_bits) false match)
+    // floor(n / P), floor(n / SP) for n * divisor < 2^32 by one multiply-high (magic = floor(2^32 / divisor) + 1): the probes per table
+    // and the pieces per partition are launch constants only the host knows, and a 32-bit division is ~35 instructions on this
+    // machine — three of them per staged row
+    const uint32_t magic_P = (P > 1) ? 0xFFFFFFFFu / static_cast<uint32_t>(P) + 1u : 0u;
+    // (global-arena mode only — the long lists, where staging is 35 rows per wave; the LDS-mode kernel keeps the plain division: with the
+    // cheap one the compiler keeps twelve rows' coordinates alive across the loads and the kernel spills)
+    auto div_P = [&](int n) -> int { if constexpr (kLds) return n / P; else return (P > 1) ? static_cast<int>(__umulhi(static_cast<uint32_t>(n), magic_P)) : n; };
     const uint32_t seq_mask = (1u << prm.seq_bits) - 1u;
     const uint32_t tag_max = (0xFFFFFFFFu >> prm.seq_bits) - 1u;   // keeps every entry != kHtEmpty
     auto id_tag = [&](int32_t id) -> uint32_t {
@@ -531,6 +538,8 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
         // coalesced 256-byte row; kStageU iterations are in flight per wave.
         {
             const int SP = (S + 63) >> 6;                 // 64-lane pieces per partition
+            const uint32_t magic_SP = (SP > 1) ? 0xFFFFFFFFu / static_cast<uint32_t>(SP) + 1u : 0u;
+            auto div_SP = [&](int n) -> int { if constexpr (kLds) return n / SP; else return (SP > 1) ? static_cast<int>(__umulhi(static_cast<uint32_t>(n), magic_SP)) : n; };
             const int nitems = TP * SP;
             const int nwv = nthreads >> 6;
             for (int it0 = wave; it0 < nitems; it0 += nwv * kStageU) {
@@ -540,8 +549,8 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                     const int it = it0 + u * nwv;
                     idv[u] = -1;
                     if (it < nitems) {
-                        const int ts = it / SP, pos = (it - ts * SP) * 64 + lane;
-                        const int td = ts / P, step = ts - td * P;
+                        const int ts = div_SP(it), pos = (it - ts * SP) * 64 + lane;
+                        const int td = div_P(ts), step = ts - td * P;
                         const int4 pr = probe[ts];
                         if (step < nprobe[td] && pos < pr.w && pos < S) idv[u] = prm.ids[ids_base[td] + pr.z + pos];
                     }
@@ -550,7 +559,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 for (int u = 0; u < kStageU; u++) {
                     const int it = it0 + u * nwv;
                     if (it >= nitems) continue;           // wave-uniform
-                    const int ts = it / SP, pos = (it - ts * SP) * 64 + lane;
+                    const int ts = div_SP(it), pos = (it - ts * SP) * 64 + lane;
                     if (pos >= S) continue;
                     const int j = ts * S + pos;
                     int32_t id = idv[u];
@@ -651,7 +660,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                             fseq[j] = f;
                             atomicSub(&bins[v & 0x3FFF], 1);
                             atomicSub(&stepcnt[ts], 1);
-                            atomicAdd(&dupcnt[ts / P], 1);
+                            atomicAdd(&dupcnt[div_P(ts)], 1);
                         }
                       }
                     }
@@ -708,7 +717,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                 const int ts = FSP_TS(j);
                 atomicSub(&bins[v & 0x3FFF], 1);
                 atomicSub(&stepcnt[ts], 1);
-                atomicAdd(&dupcnt[ts / P], 1);
+                atomicAdd(&dupcnt[div_P(ts)], 1);
             }
         } else {
             for (int j = tid; j < prm.max_tuples; j += nthreads) tscore[j] &= ~kFirstFlag;
@@ -726,7 +735,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
             __syncthreads();
             for (int j = tid; j < prm.max_tuples; j += nthreads) {
                 const uint16_t v = tscore[j];
-                if ((v & kLiveFlag) && !(v & kFirstFlag)) atomicAdd(&dupcnt[FSP_TS(j) / P], 1);
+                if ((v & kLiveFlag) && !(v & kFirstFlag)) atomicAdd(&dupcnt[div_P(FSP_TS(j))], 1);
             }
         }
         __syncthreads();
@@ -753,7 +762,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
                     const uint16_t v = tscore[j];
                     if (!(v & kLiveFlag) || FSP_TS(j) <= cut) continue;
                     if (v & kFirstFlag) atomicSub(&bins[v & 0x3FFF], 1);
-                    else atomicSub(&dupcnt[FSP_TS(j) / P], 1);
+                    else atomicSub(&dupcnt[div_P(FSP_TS(j))], 1);
                     tscore[j] = 0;
                 }
                 __syncthreads();
@@ -769,7 +778,7 @@ __device__ __forceinline__ void route_select_query(const RouteParams& prm, unsig
 
         // ---- B3: repeated occurrences: min score + strict improvements in table order (PIS:744-750) --
         bool b3_done = false;
-        if (sliced && !prm.out_raw) {
+        if (!kLds && sliced && !prm.out_raw) {
             // Nobody asked for rawSeen (the search path never does: it is a profiler counter of the reference, PIS:744-750), so all
             // that is needed is every id's LOWEST score — no order among its repeats, no table phases: the live repeats are listed
             // once (LDS region, free between the hash build and the ordering: (score | tuple, first occurrence) per repeat), every
