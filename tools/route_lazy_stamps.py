@@ -6,8 +6,15 @@ pkg = g.load_package()
 if os.environ.get('AB_LIB'): pkg._native._SO = os.path.abspath(os.environ['AB_LIB'])
 n, d, T, D, m, lam, B, Q = 1_000_000, 128, 16, 1, 16, 2, 256, 1024
 rng = np.random.default_rng(1)
-X = rng.standard_normal((n, d), dtype=np.float32)
-Qh = np.random.default_rng(2).standard_normal((Q, d), dtype=np.float32)
+if os.environ.get("DATA"):          # bench.py's generators: clustered | siftlike:16:6
+    import importlib.util
+    _sp = importlib.util.spec_from_file_location("fspann_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    _b = importlib.util.module_from_spec(_sp); _sp.loader.exec_module(_b)
+    X, _Q, _ = _b.make_data(os.environ["DATA"], n, d, 1, Q, 13, 0)
+    Qh = np.ascontiguousarray(_Q[0])
+else:
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Qh = np.random.default_rng(2).standard_normal((Q, d), dtype=np.float32)
 ctx = pkg.FspannContext(pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=lam, dim=d, refinement_limit=B), 0)
 ctx.registry_initialize(X[:1000].astype(np.float64)); ctx.set_id_meta(n); ctx.build_index(X)
 codes = torch.from_numpy(ctx.encode(Qh).view(np.int64)).cuda()
