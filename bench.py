@@ -1335,7 +1335,25 @@ def main():
                     treeified=cj.get("treeified"), wall_s=round(time.perf_counter() - t_c, 1))
             except Exception as e:      # a report beside the line, never a reason to lose it
                 shipped_out[wname] = dict(error=str(e)[:300])
-        extra = dict(shipped_profiles=shipped_out,
+        # ... and the HEADLINE configuration itself on the SIFT-like data (north_star quotes throughput on random Gaussian vectors, where no
+        # LSH has signal: this line says what the same kernels do when the tables agree on some candidates, and what recall B = 256 buys)
+        other = {}
+        if args.data == "gaussian" and args.workload == "sift1m_T16_b32_B256_Q1024":
+            cmd = [sys.executable, os.path.abspath(__file__), "--data", args.shipped_data, "--steps", "200", "--warmup", "10", "--no-shipped", "--no-extras",
+                   "--no-cpu-baseline"]
+            try:
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                line = [x for x in pr.stdout.splitlines() if x.startswith("{")]
+                if pr.returncode == 0 and line:
+                    cj = json.loads(line[-1])
+                    other = dict(value=cj["value"], unit=cj["unit"], ms_per_step=cj["ms_per_step"], steps=cj["steps"], data=cj["data"],
+                                 recall_at_10=cj.get("recall_at_10"), distance_ratio_at_10=cj.get("distance_ratio_at_10"), stages_ms=cj.get("stages_ms"),
+                                 scan_frac=(cj.get("roofline") or {}).get("frac"), route=(cj.get("route_stage") or {}).get("kernels"))
+                else:
+                    other = dict(error=("rc %d: " % pr.returncode) + pr.stderr[-400:])
+            except Exception as e:
+                other = dict(error=str(e)[:300])
+        extra = dict(shipped_profiles=shipped_out, headline_config_on_siftlike_data=other,
                      note="the reference's shipped SIFT1M profiles run by this same command as child processes (full select + chunked scan + "
                           "merge, three kernels per step on three contexts); `value` above is untouched by them")
 
