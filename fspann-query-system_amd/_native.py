@@ -111,6 +111,7 @@ _SIGS = {
     "fspann_set_gfunctions": (_i, [_vp, _vp, _vp, _vp]),
     "fspann_registry_initialize": (_i, [_vp, _vp, _i64, _i64]),
     "fspann_get_gfunctions": (_i, [_vp, _vp, _vp, _vp]),
+    "fspann_host_buffer": (_vp, [_vp, _sz]),
     "fspann_set_index": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fspann_set_id_meta": (_i, [_vp, _i64, _vp, _vp]),
     "fspann_finalize": (_i, [_vp]),

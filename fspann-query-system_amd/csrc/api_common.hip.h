@@ -41,9 +41,18 @@ template <typename T> void free_devt(T*& p) {
 constexpr size_t kPinBytes = size_t(1) << 20;
 // the context's pinned block (allocated at the first small host-pointer call; false: none, the general path runs)
 bool pin_block(fspann_ctx* c) {
-    if (!c->h_pin && hipHostMalloc(&c->h_pin, kPinBytes, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; (void)hipGetLastError(); }
+    if (!c->h_pin) {
+        if (hipHostMalloc(&c->h_pin, kPinBytes, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; (void)hipGetLastError(); }
+        else if (hipHostGetDevicePointer(&c->d_pin, c->h_pin, 0) != hipSuccess) { c->d_pin = nullptr; (void)hipGetLastError(); }
+    }
     return c->h_pin != nullptr;
 }
+// Calls of a handful of queries (QueryService.search is one token per call, ForwardSecureANNSystem.java:636): the kernels read their
+// arguments from the pinned block and write their results into it THROUGH THE BUS — no copy command either way, one launch sequence and
+// one synchronisation (a copy command costs ~8 us of the stream's time whatever its size; a few KB written by the kernel itself cost
+// less).  More queries than this go through the block with one copy each way: thousands of scattered 4-byte stores over PCIe do not.
+constexpr int64_t kZeroCopyMaxQ = 4;
+bool zero_copy_ok(fspann_ctx* c, int64_t nq) { return nq <= kZeroCopyMaxQ && c->knob_zero_copy && pin_block(c) && c->d_pin != nullptr; }
 
 int resolve_unmodelled(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit, int64_t cap, int32_t* ids_dev,
                        int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev, int32_t* raw_dev, int64_t* resolved_out, int64_t* left_out);   // api_ext.hip.h

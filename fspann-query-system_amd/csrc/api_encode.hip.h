@@ -101,6 +101,24 @@ int fspann_encode(fspann_ctx* c, int64_t nq, const void* q, int dtype, uint64_t*
     const size_t hb = hashes ? static_cast<size_t>(nq) * c->P_total * 4 : 0;
     return guarded([&]() -> int {
     int rc;
+    {   // a handful of queries (QueryTokenFactory.create is one vector per call): through the mapped pinned block, no copy commands
+        auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+        const size_t o_c = al(qb), o_b = o_c + al(cb), o_h = o_b + al(static_cast<size_t>(nq) * 4), tot = o_h + al(hb);
+        if (tot <= kPinBytes && zero_copy_ok(c, nq)) {
+            unsigned char* hp = static_cast<unsigned char*>(c->h_pin), *dp = static_cast<unsigned char*>(c->d_pin);
+            std::memcpy(hp, q, qb);
+            rc = fspann_encode_dev(c, nq, dp, dtype, reinterpret_cast<uint64_t*>(dp + o_c), hashes ? reinterpret_cast<int32_t*>(dp + o_h) : nullptr,
+                                   reinterpret_cast<int32_t*>(dp + o_b));
+            if (rc) return rc;
+            FSP_HIP(hipStreamSynchronize(c->stream));
+            const int32_t* bad = reinterpret_cast<const int32_t*>(hp + o_b);
+            for (int64_t i = 0; i < nq; i++)
+                if (bad[i]) return fail(FSPANN_E_ARG, "Vector contains NaN/Inf (query %lld)", (long long)i);  // Coding.java:360
+            std::memcpy(codes, hp + o_c, cb);
+            if (hashes) std::memcpy(hashes, hp + o_h, hb);
+            return FSPANN_OK;
+        }
+    }
     if ((rc = ensure(c, c->ws_io[0], qb))) return rc;
     if ((rc = ensure(c, c->ws_io[1], cb))) return rc;
     if ((rc = ensure(c, c->ws_io[2], static_cast<size_t>(nq) * 4))) return rc;

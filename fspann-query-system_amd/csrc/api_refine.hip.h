@@ -189,26 +189,33 @@ int fspann_refine(fspann_ctx* c, int64_t nq, const void* q, const void* cand, in
         const size_t up = al(qb) + al(ib) + al(nb), down = al(ob_d) + al(ob_i) + al(2 * nb);
         if (std::max(up, down) <= kPinBytes && pin_block(c)) {
             unsigned char* hp = static_cast<unsigned char*>(c->h_pin);
-            if ((rc = ensure(c, c->ws_io[0], up))) return rc;
+            // a handful of queries: query, ids and counts are read from the mapped pinned block and the results written into it by the
+            // kernel itself (zero_copy_ok); the rows always travel by a copy command (a workgroup reading 256 KB over the bus is slow)
+            const bool zc = al(up) + down <= kPinBytes && zero_copy_ok(c, nq);
+            if (!zc) {
+                if ((rc = ensure(c, c->ws_io[0], up))) return rc;
+                if ((rc = ensure(c, c->ws_io[4], down))) return rc;
+            }
             if ((rc = ensure(c, c->ws_io[1], cb))) return rc;
-            if ((rc = ensure(c, c->ws_io[4], down))) return rc;
-            unsigned char* du = static_cast<unsigned char*>(c->ws_io[0].p), *dd = static_cast<unsigned char*>(c->ws_io[4].p);
+            unsigned char* du = zc ? static_cast<unsigned char*>(c->d_pin) : static_cast<unsigned char*>(c->ws_io[0].p);
+            unsigned char* dd = zc ? static_cast<unsigned char*>(c->d_pin) + al(up) : static_cast<unsigned char*>(c->ws_io[4].p);
+            unsigned char* hres = zc ? hp + al(up) : hp;
             std::memcpy(hp, q, qb);
             std::memcpy(hp + al(qb), cand_ids, ib);
             std::memcpy(hp + al(qb) + al(ib), cand_count, nb);
-            FSP_HIP(hipMemcpyAsync(du, hp, up, hipMemcpyHostToDevice, c->stream));
+            if (!zc) FSP_HIP(hipMemcpyAsync(du, hp, up, hipMemcpyHostToDevice, c->stream));
             FSP_HIP(hipMemcpyAsync(c->ws_io[1].p, cand, cb, hipMemcpyHostToDevice, c->stream));
             int32_t* cnt_out = reinterpret_cast<int32_t*>(dd + al(ob_d) + al(ob_i));
             rc = fspann_refine_dev(c, nq, du, dtype, c->ws_io[1].p, dtype, B, reinterpret_cast<int32_t*>(du + al(qb)),
                                    reinterpret_cast<int32_t*>(du + al(qb) + al(ib)), k, reinterpret_cast<int32_t*>(dd + al(ob_d)),
                                    reinterpret_cast<double*>(dd), cnt_out, cnt_out + nq);
             if (rc) return rc;
-            FSP_HIP(hipMemcpyAsync(hp, dd, down, hipMemcpyDeviceToHost, c->stream));   // (stream order: the way up has been read by then)
+            if (!zc) FSP_HIP(hipMemcpyAsync(hp, dd, down, hipMemcpyDeviceToHost, c->stream));   // (stream order: the way up has been read by then)
             FSP_HIP(hipStreamSynchronize(c->stream));
-            std::memcpy(out_dist, hp, ob_d);
-            std::memcpy(out_ids, hp + al(ob_d), ob_i);
-            std::memcpy(out_count, hp + al(ob_d) + al(ob_i), nb);
-            if (scored) std::memcpy(scored, hp + al(ob_d) + al(ob_i) + nb, nb);
+            std::memcpy(out_dist, hres, ob_d);
+            std::memcpy(out_ids, hres + al(ob_d), ob_i);
+            std::memcpy(out_count, hres + al(ob_d) + al(ob_i), nb);
+            if (scored) std::memcpy(scored, hres + al(ob_d) + al(ob_i) + nb, nb);
             return FSPANN_OK;
         }
     }
@@ -232,6 +239,27 @@ int fspann_refine(fspann_ctx* c, int64_t nq, const void* q, const void* cand, in
     if (scored) FSP_HIP(hipMemcpyAsync(scored, cnts + 2 * nq, nb, hipMemcpyDeviceToHost, c->stream));
     FSP_HIP(hipStreamSynchronize(c->stream));
     return FSPANN_OK;
+}
+
+void* fspann_host_buffer(fspann_ctx* c, size_t bytes) {
+    if (!c) { fail(FSPANN_E_NULL, "ctx is null"); return nullptr; }
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); fail(FSPANN_E_DEVICE, "hipSetDevice(%d) failed", c->device); return nullptr; }
+    if (bytes == 0) bytes = 16;
+    if (bytes > c->h_rows_bytes) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess) (void)hipGetLastError();      // nothing in flight may still read the old block
+        if (c->h_rows) (void)hipHostFree(c->h_rows);
+        c->h_rows = nullptr; c->h_rows_bytes = 0;
+        const size_t want = (bytes + 4095) & ~size_t(4095);
+        if (hipHostMalloc(&c->h_rows, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_rows = nullptr;
+            fail(FSPANN_E_NOMEM, "cannot pin %zu bytes of host memory", want);
+            return nullptr;
+        }
+        c->h_rows_bytes = want;
+    }
+    return c->h_rows;
 }
 
 // ---- plaintext store (test / bench harness) ----------------------------------------------

@@ -314,32 +314,40 @@ int fspann_route(fspann_ctx* c, int64_t nq, const uint64_t* codes, int probe_ove
     const size_t ob_a = (ob + 15) & ~size_t(15), cnt_a = (static_cast<size_t>(nq) * 12 + 15) & ~size_t(15);
     if (std::max(cb, 2 * ob_a + cnt_a) <= kPinBytes && pin_block(c)) {
         unsigned char* hp = static_cast<unsigned char*>(c->h_pin);
-        if ((rc = ensure(c, c->ws_io[0], cb))) return rc;
-        if ((rc = ensure(c, c->ws_io[1], 2 * ob_a + cnt_a))) return rc;       // ids | scores | count, kept, rawSeen: one block
-        unsigned char* dv = static_cast<unsigned char*>(c->ws_io[1].p);
+        const size_t cb_a = (cb + 15) & ~size_t(15);
+        // a handful of queries: the kernels read the codes from the mapped pinned block and write lists and counts into it (no copy
+        // commands: zero_copy_ok); else one copy each way through device buffers
+        const bool zc = cb_a + 2 * ob_a + cnt_a <= kPinBytes && zero_copy_ok(c, nq);
+        if (!zc) {
+            if ((rc = ensure(c, c->ws_io[0], cb))) return rc;
+            if ((rc = ensure(c, c->ws_io[1], 2 * ob_a + cnt_a))) return rc;       // ids | scores | count, kept, rawSeen: one block
+        }
+        unsigned char* hres = zc ? hp + cb_a : hp;                                  // where the results end up on the host
+        unsigned char* dv = zc ? static_cast<unsigned char*>(c->d_pin) + cb_a : static_cast<unsigned char*>(c->ws_io[1].p);
+        const uint64_t* codes_d = zc ? static_cast<const uint64_t*>(c->d_pin) : static_cast<const uint64_t*>(c->ws_io[0].p);
         int32_t* ids_d = reinterpret_cast<int32_t*>(dv), *sc_d = reinterpret_cast<int32_t*>(dv + ob_a), *cnt_d = reinterpret_cast<int32_t*>(dv + 2 * ob_a);
         std::memcpy(hp, codes, cb);
-        FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, hp, cb, hipMemcpyHostToDevice, c->stream));
-        rc = fspann_route_dev(c, nq, static_cast<const uint64_t*>(c->ws_io[0].p), probe_override, limit, cap, ids_d, sc_d, cnt_d,
+        if (!zc) FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, hp, cb, hipMemcpyHostToDevice, c->stream));
+        rc = fspann_route_dev(c, nq, codes_d, probe_override, limit, cap, ids_d, sc_d, cnt_d,
                               kept ? cnt_d + nq : nullptr, raw_seen ? cnt_d + 2 * nq : nullptr);
         if (rc) return rc;
         for (int pass = 0; pass < 2; pass++) {
-            FSP_HIP(hipMemcpyAsync(hp, dv, 2 * ob_a + cnt_a, hipMemcpyDeviceToHost, c->stream));
+            if (!zc) FSP_HIP(hipMemcpyAsync(hp, dv, 2 * ob_a + cnt_a, hipMemcpyDeviceToHost, c->stream));
             FSP_HIP(hipStreamSynchronize(c->stream));
-            const int32_t* cnt_h = reinterpret_cast<const int32_t*>(hp + 2 * ob_a);
+            const int32_t* cnt_h = reinterpret_cast<const int32_t*>(hres + 2 * ob_a);
             bool flagged = false;
             for (int64_t i = 0; i < nq; i++) flagged = flagged || cnt_h[i] < 0;
             if (!flagged || pass == 1) break;
             // (rare) a bestScore map treeified a bin: finished by the literal JDK model on the host, then fetched again
             rc = guarded([&]() -> int {
-                return resolve_unmodelled(c, nq, static_cast<const uint64_t*>(c->ws_io[0].p), probe_override, limit, cap, ids_d, sc_d, cnt_d,
+                return resolve_unmodelled(c, nq, codes_d, probe_override, limit, cap, ids_d, sc_d, cnt_d,
                                           kept ? cnt_d + nq : nullptr, raw_seen ? cnt_d + 2 * nq : nullptr, nullptr, nullptr);
             });
             if (rc) return rc;
         }
-        const int32_t* cnt_h = reinterpret_cast<const int32_t*>(hp + 2 * ob_a);
-        std::memcpy(ids, hp, ob);
-        if (score) std::memcpy(score, hp + ob_a, ob);
+        const int32_t* cnt_h = reinterpret_cast<const int32_t*>(hres + 2 * ob_a);
+        std::memcpy(ids, hres, ob);
+        if (score) std::memcpy(score, hres + ob_a, ob);
         std::memcpy(count, cnt_h, static_cast<size_t>(nq) * 4);
         if (kept) std::memcpy(kept, cnt_h + nq, static_cast<size_t>(nq) * 4);
         if (raw_seen) std::memcpy(raw_seen, cnt_h + 2 * nq, static_cast<size_t>(nq) * 4);

@@ -294,6 +294,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_slice = env_int("FSPANN_ROUTE_SLICE", 1) != 0;
         c->knob_shape_spec = env_int("FSPANN_ROUTE_SHAPE_SPEC", 1) != 0;
         c->knob_route_lds_kb = env_int("FSPANN_ROUTE_LDS_KB", 0);
+        c->knob_zero_copy = env_int("FSPANN_ZERO_COPY", 1) != 0;
         c->knob_route_wgs = env_int("FSPANN_ROUTE_WGS", 0);
         c->knob_refine_run = env_int("FSPANN_REFINE_RUN", 1) != 0;
         c->knob_devflags = env_int("FSPANN_ROUTE_DEVFLAGS", 0);
@@ -353,6 +354,7 @@ void fspann_ctx_destroy(fspann_ctx* c) {
     for (hipEvent_t e : c->rt_events) (void)hipEventDestroy(e);
     for (auto& b : c->ws_io) free_dev(b.p);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_rows) (void)hipHostFree(c->h_rows);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     if (parent) {

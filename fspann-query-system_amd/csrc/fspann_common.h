@@ -103,6 +103,7 @@ struct fspann_ctx {
     int knob_tick_front = 100;       // FSPANN_TICK_FRONT: percent of a tick's Route workgroups that head the grid
     int knob_bincheck = -1;          // FSPANN_ROUTE_BINCHECK: the bounded select's exact treeify check (-1: on for opaque ids, off for decimal ordinals; 0 / 1 force)
     bool knob_shape_spec = true;     // FSPANN_ROUTE_SHAPE_SPEC=0: the bounded select's build with run-time tables x probes also for 16 x 5 (dev A/B)
+    bool knob_zero_copy = true;      // FSPANN_ZERO_COPY=0: tiny host-pointer calls go through copy commands like larger ones (dev A/B)
     int knob_route_lds_kb = 0;       // FSPANN_ROUTE_LDS_KB: LDS the full select may plan with (0 = all of it); less leaves room for scan workgroups beside it
     int knob_route_wgs = 0;          // FSPANN_ROUTE_WGS: workgroups per CU of the full select's grid (0 = what fits, at most 4)
     int knob_devflags = 0;           // FSPANN_ROUTE_DEVFLAGS: dev A/B switches of the full select (route.hip.h)
@@ -185,6 +186,9 @@ struct fspann_ctx {
     int fix_next = 0;
     fspann::DevBuf ws_io[8];   // staging for the host-pointer entry points
     void* h_pin = nullptr;     // pinned host block (kPinBytes) for the small transfers of the host-pointer entry points: one H2D and one D2H
+    void* d_pin = nullptr;     // the same block as the device sees it (mapped host memory): kernels of the tiniest calls read and write it directly
+    void* h_rows = nullptr;    // fspann_host_buffer: pinned host memory the adapter packs decrypted rows into (grown on demand)
+    size_t h_rows_bytes = 0;
                                //   per call instead of one synchronous pageable copy per argument (a per-query caller pays each of them)
     // transient, set by fspann_tick_dev around a refine-only tick: device-resident RouteParams of the batch's hand-over buffer
     // (the streaming scan then finishes PENDING queries itself), the LDS its full select needs, and whether a launch took it

@@ -323,6 +323,16 @@ class FspannContext:
                                      _p(out_dist), _p(out_count), _p(scored)))
         return dict(ids=out_ids, dist=out_dist, count=out_count, scored=scored)
 
+    def host_buffer(self, shape, dtype=np.float64):
+        """A numpy view of the context's PINNED host block (fspann_host_buffer), at least as large as `shape` x `dtype`: what the adapter
+        packs decrypted candidate rows into (QSI:238-271) — rows handed to refine() from here travel by plain DMA.  The view dies with the
+        next larger request or with the context."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.L.fspann_host_buffer(self._h, max(n, 16))
+        if not p:
+            raise MemoryError(self.L.fspann_last_error().decode())
+        return np.frombuffer((C.c_char * n).from_address(p), dtype=dtype).reshape(shape)
+
     def refine_store(self, q, cand_ids, cand_count, k):
         """Refine with rows read from the resident store by id (no staging copy)."""
         ci = _c(cand_ids, np.int32)

@@ -224,6 +224,11 @@ int fspann_last_route_info(fspann_ctx* ctx, int* lazy, int* overflowed);
 int fspann_refine(fspann_ctx* ctx, int64_t nq, const void* q, const void* cand, int dtype, int64_t B,
                   const int32_t* cand_ids, const int32_t* cand_count, int k, int32_t* out_ids, double* out_dist,
                   int32_t* out_count, int32_t* scored);
+/* Pinned host memory owned by the context, at least `bytes` long (grown on demand — an earlier pointer dies with a growth —, freed
+ * with the context; NULL + fspann_last_error on failure): what the adapter packs the decrypted candidate rows into in place of
+ * QSI's ArrayList<double[]> (QSI:238-271; GpuQueryServiceImpl wraps it in a direct ByteBuffer and hands that to fspann_refine).
+ * Rows that start in pinned memory reach the GPU by plain DMA; rows in pageable memory go through the runtime's staging copies. */
+void* fspann_host_buffer(fspann_ctx* ctx, size_t bytes);
 int fspann_refine_dev(fspann_ctx* ctx, int64_t nq, const void* q_dev, int q_dtype, const void* cand_dev,
                       int cand_dtype, int64_t B, const int32_t* cand_ids_dev, const int32_t* cand_count_dev, int k,
                       int32_t* out_ids_dev, double* out_dist_dev, int32_t* out_count_dev, int32_t* scored_dev);

@@ -21,6 +21,7 @@ typedef jarray jobjectArray;
 #define JNICALL
 struct JNIEnv {
     void* GetDirectBufferAddress(jobject);
+    jobject NewDirectByteBuffer(void*, jlong);
     jsize GetArrayLength(jarray);
     void GetIntArrayRegion(jintArray, jsize, jsize, jint*);
     void GetLongArrayRegion(jlongArray, jsize, jsize, jlong*);

@@ -136,6 +136,8 @@ def main():
             jret, jniret = "String", "jstring"
         elif rett in ("size_t", "int64_t"):
             jret, jniret = "long", "jlong"
+        elif rett == "void*" and name == "fspann_host_buffer":
+            jret, jniret = "ByteBuffer", "jobject"      # the pinned block itself, as a direct buffer the adapter fills in place
         elif rett == "void*":
             jret, jniret = "long", "jlong"
         else:
@@ -204,6 +206,10 @@ def main():
             cpp.append(f"    const char* r_ = {call};")
             cpp += post
             cpp.append("    return env->NewStringUTF(r_ ? r_ : \"\");")
+        elif jniret == "jobject":
+            cpp.append(f"    void* r_ = {call};")
+            cpp += post
+            cpp.append("    return r_ ? env->NewDirectByteBuffer(r_, static_cast<jlong>(bytes)) : nullptr;")
         elif rett == "void*":
             cpp.append(f"    jlong r_ = L({call});")
             cpp += post
@@ -212,8 +218,8 @@ def main():
             cpp.append(f"    {jniret} r_ = static_cast<{jniret}>({call});")
             cpp += post
             cpp.append("    return r_;")
-        if not kinds or all(k not in ("buffer", "string", "out_handle", "cfg", "tick", "out_string", "out_ptr", "out_int", "out_long", "out_double")
-                            for k, _, _ in kinds):
+        if jniret != "jobject" and (not kinds or all(k not in ("buffer", "string", "out_handle", "cfg", "tick", "out_string", "out_ptr", "out_int", "out_long", "out_double")
+                            for k, _, _ in kinds)):
             cpp.insert(len(cpp) - (len(pre) + len(post) + (1 if jniret == "void" else 2)), "    (void)env;")
         cpp.append("}")
         cpp.append("")
