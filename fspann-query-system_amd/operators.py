@@ -546,7 +546,9 @@ class QueryServiceImpl:
                 if not rows:
                     return []
                 B = len(rows)
-                res = idx.ctx.refine(qVec[None], np.stack(rows)[None], np.arange(B, dtype=np.int32)[None],
+                packed = idx.ctx.host_buffer((1, B, len(qVec)), np.float64)     # the context's pinned block (fspann_host_buffer): one DMA
+                packed[0] = np.stack(rows)
+                res = idx.ctx.refine(qVec[None], packed, np.arange(B, dtype=np.int32)[None],
                                      np.array([B], np.int32), K)          # stage B distances + C on the GPU
                 eff = int(res["count"][0])
                 out = [QueryResult(rids[j], float(dd)) for j, dd in zip(res["ids"][0, :eff], res["dist"][0, :eff])]
@@ -624,7 +626,7 @@ class QueryServiceImpl:
                 if scored:
                     Bm = max(len(rows_all[i]) for i in scored)
                     dim = len(qvecs[scored[0]])
-                    cand = np.zeros((len(scored), Bm, dim), np.float64)
+                    cand = idx.ctx.host_buffer((len(scored), Bm, dim), np.float64)   # pinned; rows beyond a query's count are never read as valid
                     cnt = np.zeros(len(scored), np.int32)
                     for j, i in enumerate(scored):
                         cand[j, :len(rows_all[i])] = np.stack(rows_all[i])

@@ -51,6 +51,14 @@ public final class GpuQueryServiceImpl implements QueryService {
     }
 
     private static ByteBuffer buf(long bytes) { return GpuPartitionedIndexService.buf(bytes); }   // refuses sizes beyond a Java buffer
+    /** The native context's PINNED block as a direct buffer (fspann_host_buffer): the decrypted rows are packed straight into it and
+     *  reach the GPU by one DMA; a JVM direct buffer is pageable memory and goes through the runtime's staging copies. */
+    private ByteBuffer pinned(long bytes) {
+        if (bytes < 0 || bytes > Integer.MAX_VALUE) throw new IllegalArgumentException("pinned buffer of " + bytes + " bytes: hand the data over in pieces");
+        ByteBuffer b = FspannNative.hostBuffer(index.nativeContext(), Math.max(bytes, 16));
+        if (b == null) throw new OutOfMemoryError(FspannNative.lastError());
+        return b.order(java.nio.ByteOrder.nativeOrder());
+    }
 
     private static boolean isValid(double[] v) {                                // QSI:407-413
         if (v == null) return false;
@@ -90,7 +98,7 @@ public final class GpuQueryServiceImpl implements QueryService {
                 if (fq.isEmpty()) { lastReturned = 0; return Collections.emptyList(); }
                 // stage B, host part — exactly the reference's loop (QSI:238-271): load, decrypt with the point's own version, validate
                 final long td0 = System.nanoTime();
-                ByteBuffer rows = buf(8L * fq.size() * dim), ids = buf(4L * fq.size());
+                ByteBuffer rows = pinned(8L * fq.size() * dim), ids = buf(4L * fq.size());
                 List<String> rowId = new ArrayList<>(fq.size());
                 for (GpuPartitionedIndexService.CandidateWithScore c : fq) {
                     try {
@@ -194,7 +202,7 @@ public final class GpuQueryServiceImpl implements QueryService {
                 for (List<GpuPartitionedIndexService.CandidateWithScore> fq : fqs) bmax = Math.max(bmax, fq.size());
                 if (bmax == 0) break;
                 final int dim = qv[active.get(0)].length, na = active.size();
-                ByteBuffer rows = buf(8L * na * bmax * dim), ids = buf(4L * na * bmax), cnt = buf(4L * na), qb = buf(8L * na * dim);
+                ByteBuffer rows = pinned(8L * na * bmax * dim), ids = buf(4L * na * bmax), cnt = buf(4L * na), qb = buf(8L * na * dim);
                 List<List<String>> rowIds = new ArrayList<>(na);
                 for (int a = 0; a < na; a++) {
                     final int i = active.get(a);
