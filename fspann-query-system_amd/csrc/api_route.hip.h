@@ -234,23 +234,8 @@ int launch_route_probe(fspann_ctx* c, const RouteParams& p, const RoutePlan& pl)
     return FSPANN_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit,
-                     int64_t cap, int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev,
-                     int32_t* raw_seen_dev) {
-    CHECK_CTX(c);
-    if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");  // PIS:594
-    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
-    if (nq == 0) return FSPANN_OK;
-    RoutePlan pl;
-    RouteParams p{};
-    bool fused = false;
-    int rc = prepare_route(c, nq, codes_dev, probe_override, limit, cap, ids_dev, score_dev, count_dev, kept_dev, raw_seen_dev, &pl, &p, &fused);
-    if (rc) return rc;
-    if (!fused && (rc = launch_route_probe(c, p, pl))) return rc;
+// the full select (every query, or — qcount / qlist set — the queries the bounded select handed over)
+int launch_full_select(fspann_ctx* c, const RoutePlan& pl, const RouteParams& p) {
 #define FSP_LAUNCH_SEL(LDS, THR)                                                                                         \
     do {                                                                                                                 \
         auto kern = route_select_kernel<LDS, THR>;                                                                       \
@@ -262,6 +247,29 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
         }                                                                                                                \
         hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(THR), pl.lds_bytes, c->stream, p, p.probe_g, p.nprobe_g);           \
     } while (0)
+    if (pl.lds_mode) { if (pl.threads == 1024) FSP_LAUNCH_SEL(true, 1024); else FSP_LAUNCH_SEL(true, 512); }
+    else { if (pl.threads == 1024) FSP_LAUNCH_SEL(false, 1024); else FSP_LAUNCH_SEL(false, 512); }
+#undef FSP_LAUNCH_SEL
+    FSP_HIP(hipGetLastError());
+    return FSPANN_OK;
+}
+
+// fspann_route_dev.  deferred (optional): when the bounded select runs, the launch that finishes the queries it hands over — none,
+// normally — is NOT issued; its plan and parameters are returned instead and the caller issues it (launch_full_select) once it has
+// seen a PENDING count (fspann_route's calls of a handful of queries: one launch less in front of the synchronisation).
+int route_dev_impl(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit,
+                   int64_t cap, int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev,
+                   int32_t* raw_seen_dev, RoutePlan* deferred_pl = nullptr, RouteParams* deferred_p = nullptr, bool* deferred = nullptr) {
+    if (deferred) *deferred = false;
+    if (!c->frozen) return fail(FSPANN_E_STATE, "Index not finalized");  // PIS:594
+    if (nq < 0) return fail(FSPANN_E_ARG, "nq < 0");
+    if (nq == 0) return FSPANN_OK;
+    RoutePlan pl;
+    RouteParams p{};
+    bool fused = false;
+    int rc = prepare_route(c, nq, codes_dev, probe_override, limit, cap, ids_dev, score_dev, count_dev, kept_dev, raw_seen_dev, &pl, &p, &fused);
+    if (rc) return rc;
+    if (!fused && (rc = launch_route_probe(c, p, pl))) return rc;
     c->last_route_lazy = pl.lazy;
     if (pl.lazy) {
         if (pl.lz_entries == 512) {
@@ -289,12 +297,20 @@ int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int p
         // queries the bounded select handed over (none, normally): the full select over the overflow list
         p.qcount = p.ovf_count; p.qlist = p.ovf_list;
         pl.grid = std::min(pl.grid, 32);    // normally nothing to do: keep the launch small
+        if (deferred_pl && deferred_p && deferred) { *deferred_pl = pl; *deferred_p = p; *deferred = true; return FSPANN_OK; }
     }
-    if (pl.lds_mode) { if (pl.threads == 1024) FSP_LAUNCH_SEL(true, 1024); else FSP_LAUNCH_SEL(true, 512); }
-    else { if (pl.threads == 1024) FSP_LAUNCH_SEL(false, 1024); else FSP_LAUNCH_SEL(false, 512); }
-#undef FSP_LAUNCH_SEL
-    FSP_HIP(hipGetLastError());
-    return FSPANN_OK;
+    return launch_full_select(c, pl, p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fspann_route_dev(fspann_ctx* c, int64_t nq, const uint64_t* codes_dev, int probe_override, int32_t limit,
+                     int64_t cap, int32_t* ids_dev, int32_t* score_dev, int32_t* count_dev, int32_t* kept_dev,
+                     int32_t* raw_seen_dev) {
+    CHECK_CTX(c);
+    return route_dev_impl(c, nq, codes_dev, probe_override, limit, cap, ids_dev, score_dev, count_dev, kept_dev, raw_seen_dev);
 }
 
 int fspann_route(fspann_ctx* c, int64_t nq, const uint64_t* codes, int probe_override, int32_t limit, int64_t cap,
@@ -328,9 +344,21 @@ int fspann_route(fspann_ctx* c, int64_t nq, const uint64_t* codes, int probe_ove
         int32_t* ids_d = reinterpret_cast<int32_t*>(dv), *sc_d = reinterpret_cast<int32_t*>(dv + ob_a), *cnt_d = reinterpret_cast<int32_t*>(dv + 2 * ob_a);
         std::memcpy(hp, codes, cb);
         if (!zc) FSP_HIP(hipMemcpyAsync(c->ws_io[0].p, hp, cb, hipMemcpyHostToDevice, c->stream));
-        rc = fspann_route_dev(c, nq, codes_d, probe_override, limit, cap, ids_d, sc_d, cnt_d,
-                              kept ? cnt_d + nq : nullptr, raw_seen ? cnt_d + 2 * nq : nullptr);
+        RoutePlan def_pl;
+        RouteParams def_p{};
+        bool deferred = false;
+        rc = route_dev_impl(c, nq, codes_d, probe_override, limit, cap, ids_d, sc_d, cnt_d,
+                            kept ? cnt_d + nq : nullptr, raw_seen ? cnt_d + 2 * nq : nullptr, zc ? &def_pl : nullptr, zc ? &def_p : nullptr, zc ? &deferred : nullptr);
         if (rc) return rc;
+        if (deferred) {
+            // zero-copy call, bounded select: the counts are readable right after the synchronisation — the launch for handed-over queries
+            // is issued only if one of them says PENDING (it was ~5 us of every call, for a list that is almost always empty)
+            FSP_HIP(hipStreamSynchronize(c->stream));
+            const int32_t* cnt_p = reinterpret_cast<const int32_t*>(hres + 2 * ob_a);
+            bool pending = false;
+            for (int64_t i = 0; i < nq; i++) pending = pending || cnt_p[i] == kRoutePending;
+            if (pending && (rc = launch_full_select(c, def_pl, def_p))) return rc;
+        }
         for (int pass = 0; pass < 2; pass++) {
             if (!zc) FSP_HIP(hipMemcpyAsync(hp, dv, 2 * ob_a + cnt_a, hipMemcpyDeviceToHost, c->stream));
             FSP_HIP(hipStreamSynchronize(c->stream));

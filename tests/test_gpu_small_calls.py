@@ -86,3 +86,25 @@ def test_nan_query_is_refused_in_a_single_call(pkg, oracle):
         with pytest.raises(ValueError):
             ctx.encode(q)                                   # Coding.java:360 -> IllegalArgumentException
         assert ctx.encode(np.ones((1, 8), np.float64)).shape == (1, 4, 1)
+
+
+def test_single_call_whose_bounded_select_hands_the_query_over(pkg, oracle, monkeypatch):
+    # FSPANN_ROUTE_LAZY_CAP = 64: no query fits the bounded select's size class, every one is handed to the full select — in a
+    # zero-copy call that launch is issued only after the host has seen the PENDING count
+    monkeypatch.setenv("FSPANN_ROUTE_LAZY_CAP", "64")
+    sc = make_scene(oracle, n=30000, d=24, T=4, D=4, m=12, lam=2, B=192, seed=74)
+    p, o = sc["params"], sc["oracle"]
+    Q = sc["rng"].standard_normal((9, p["d"])).astype(np.float32).astype(np.float64)
+    codes = o.encode(Q)
+    ids_o, score_o, count_o, raw_o = o.route(codes)
+    with _ctx(pkg, sc) as ctx:
+        i = 0
+        for step in (1, 2, 1, 5):
+            sl = slice(i, i + step)
+            i += step
+            rt = ctx.route(codes[sl], limit=p["B"], counters=False)
+            info = ctx.last_route_info()
+            assert info["lazy"] and info["overflowed"] == step, info
+            for j in range(step):
+                c = min(p["B"], count_o[sl][j])
+                assert rt["count"][j] == c and np.array_equal(rt["ids"][j, :c], ids_o[sl][j, :c])
