@@ -989,7 +989,7 @@ def main():
     # ---------------- roofline of the refinement scan (north_star's HBM-bound kernel) ---------------------------------------
     # algorithmic bytes per launch: Q * (B*d*4 + d*4 + k*8)
     ref_bytes = Q * (B * d * 4 + d * 4 + k * 8)
-    achieved = ref_bytes / (ref_ms * 1e-3) / 1e9
+    achieved = ref_bytes / (ref_ms * 1e-3) / 1e9 if ref_ms > 0 else 0.0      # (0: no dispatch carried events — experiments only)
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "refine_traffic.json")
     if os.path.exists(tpath):
@@ -1125,7 +1125,7 @@ def main():
                                      achieved=round(ref_bytes / (overlapped_main[1] * 1e-3) / 1e9, 1),
                                      note="the same kernel's sampled dispatches while kernels of the other contexts run beside it (what a kernel "
                                           "trace of this command averages over): it shares HBM then, so this is not a roofline of the kernel")
-                                if overlapped_main else None),
+                                if overlapped_main and overlapped_main[1] > 0 else None),
                     hbm_proof=hbm_proof, cfg4_shape=cfg4_shape, f64_rows=f64_rows)
 
     # Route (probe + select) is bound by dependent L2 rounds and LDS atomics, not by HBM or MFMA; its algorithmic bytes
