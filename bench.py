@@ -40,6 +40,10 @@ WORKLOADS = {
     "sift1m_T16_b32_B256_Q1024": dict(n=1_000_000, d=128, T=16, D=1, m=16, lam=2, B=256, Q=1024, k=10),
     # BASELINE.json configs[0]: plumbing case
     "synth10k_T8_b16_B64_Q100": dict(n=10_000, d=128, T=8, D=1, m=8, lam=2, B=64, Q=100, k=10),
+    # BASELINE.json configs[2] / [3]: ONE GPU's shard of the 8-GPU configurations (queries are sharded, the index is replicated:
+    # 4 096 / 8 and 8 192 / 8 queries per GPU and step) — parity-test cases first (tests/test_gpu_fullsize.py), measured here on request
+    "gist1m_T16_b32_B512_Q512": dict(n=1_000_000, d=960, T=16, D=1, m=16, lam=2, B=512, Q=512, k=10, nb=8),
+    "synth10m_T32_b64_B1024_Q1024": dict(n=10_000_000, d=768, T=32, D=1, m=32, lam=2, B=1024, Q=1024, k=10, nb=2),
     # The profiles the reference SHIPS and publishes its numbers at (config/src/main/resources/config_sift1m.json:44-128,
     # logs/New Results:27-57): k = 100 is eval.kVariants' maximum = the token's topK.  HARD_CAP =
     # max(maxGlobalCandidates, refinementLimit) is below T*D*P*64 for both, so the cap can cut the traversal; at P10_HIGH bestScore

@@ -5,13 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
 d, T, D, m, lam = 128, 16, 1, 16, 2
+NQS = (1024, 262144)
+if os.environ.get("SHAPE") == "cfg3": d, T, m, NQS = 960, 16, 16, (512, 4096)          # BASELINE config #3: GIST-shaped, 512 queries per GPU
+if os.environ.get("SHAPE") == "cfg4": d, T, m, NQS = 768, 32, 32, (1024, 8192)         # config #4: 32 tables x 64 bits, 1 024 queries per GPU
 rng = np.random.default_rng(1)
 S = rng.standard_normal((1000, d))
 ctx = pkg.FspannContext(pkg.PaperRuntimeConfig(tables=T, divisions=D, m=m, lambda_=lam, dim=d), 0)
 ctx.registry_initialize(S)
 F32 = pkg._native.F32
 stream = torch.cuda.ExternalStream(ctx.stream)
-for nq in (1024, 262144):
+for nq in NQS:
     q = torch.randn((nq, d), device="cuda")
     codes = torch.zeros((nq, T * D, 1), dtype=torch.int64, device="cuda")
     bad = torch.zeros(nq, dtype=torch.int32, device="cuda")
