@@ -52,8 +52,19 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
     // QB queries per block: 8 for bulk coding (index build), 4 for query batches so that
     // a 1024-query batch still fills 256 CUs.
     bool launched = false;
+    if constexpr (sizeof(TIn) == 4) {
+        // two rows per workgroup when four would leave CUs without one (BASELINE config #3's shard: 512 queries x 256 projections = 128
+        // workgroups of four rows: 59.8 -> 48.4 us); FSPANN_ENCODE_QB forces 1 / 2 / 4 / 8 (dev A/B)
+        int qb_env = c->knob_encode_qb;
+        if (qb_env == 0 && nq >= 2 && ((nq + 3) / 4) * static_cast<int64_t>(gy) < c->num_cus) qb_env = 2;
+        if (qb_env == 1 || qb_env == 2) {
+            if (qb_env == 1) hipLaunchKernelGGL((encode_exact_kernel<TIn, 1>), dim3(static_cast<unsigned>(nq), gy), dim3(kEncThreads), 0, c->stream, ea);
+            else hipLaunchKernelGGL((encode_exact_kernel<TIn, 2>), dim3(static_cast<unsigned>((nq + 1) / 2), gy), dim3(kEncThreads), 0, c->stream, ea);
+            launched = true;
+        }
+    }
     if constexpr (sizeof(TIn) == 4) {       // (8 fp64 query rows per block do not fit the register budget)
-        if (nq >= 8192) {
+        if (!launched && (nq >= 8192 || c->knob_encode_qb == 8)) {
             constexpr int QB = 8;
             hipLaunchKernelGGL((encode_exact_kernel<TIn, QB>), dim3(static_cast<unsigned>((nq + QB - 1) / QB), gy), dim3(kEncThreads), 0, c->stream, ea);
             launched = true;
