@@ -15,10 +15,18 @@ int launch_encode_mfma(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* co
     FSP_HIP(hipMemsetAsync(cnt, 0, 8, c->stream));
     // the code words start clear: the MFMA epilogue ORs in the bits of the pairs it can decide, encode_fix_kernel those of the rest
     FSP_HIP(hipMemsetAsync(codes_dev, 0, static_cast<size_t>(nq) * c->TD * c->W * 8, c->stream));
-    dim3 grid(static_cast<unsigned>((nq + kMfmaTileQ - 1) / kMfmaTileQ), static_cast<unsigned>((P + kMfmaTileP - 1) / kMfmaTileP));
     unsigned long long* cw = reinterpret_cast<unsigned long long*>(codes_dev);
-    hipLaunchKernelGGL((encode_mfma_kernel<TIn>), grid, dim3(256), 0, c->stream, q_dev, nq, d, c->d_alphaT32, c->d_r, c->d_omega, P, c->cfg.m, c->cfg.lambda,
-                       c->W, c->TD, hashes_dev, cw, bad_dev, list, cap, cnt, c->alpha_norm_max);
+    // block tile: 64 x 256 for bulk coding; 32 x 128 when that would not give every CU two blocks (query batches)
+    const int64_t big_blocks = ((nq + 63) / 64) * ((P + 255) / 256);
+    if (big_blocks >= 2 * static_cast<int64_t>(c->num_cus) && c->knob_mfma_tile != 1) {
+        dim3 grid(static_cast<unsigned>((nq + mfma_tile_q(2) - 1) / mfma_tile_q(2)), static_cast<unsigned>((P + mfma_tile_p(2) - 1) / mfma_tile_p(2)));
+        hipLaunchKernelGGL((encode_mfma_kernel<TIn, 2, 2>), grid, dim3(256), 0, c->stream, q_dev, nq, d, c->d_alphaT32, c->d_r, c->d_omega, P, c->cfg.m,
+                           c->cfg.lambda, c->W, c->TD, hashes_dev, cw, bad_dev, list, cap, cnt, c->alpha_norm_max);
+    } else {
+        dim3 grid(static_cast<unsigned>((nq + mfma_tile_q(1) - 1) / mfma_tile_q(1)), static_cast<unsigned>((P + mfma_tile_p(1) - 1) / mfma_tile_p(1)));
+        hipLaunchKernelGGL((encode_mfma_kernel<TIn, 1, 1>), grid, dim3(256), 0, c->stream, q_dev, nq, d, c->d_alphaT32, c->d_r, c->d_omega, P, c->cfg.m,
+                           c->cfg.lambda, c->W, c->TD, hashes_dev, cw, bad_dev, list, cap, cnt, c->alpha_norm_max);
+    }
     FSP_HIP(hipGetLastError());
     hipLaunchKernelGGL((encode_fix_kernel<TIn>), dim3(static_cast<unsigned>(std::min<int64_t>(1024, (cap + 255) / 256))), dim3(256), 0, c->stream,
                        q_dev, d, c->d_alphaT, c->d_r, c->d_omega, P, c->cfg.m, c->cfg.lambda, c->W, c->TD, list, cnt, cap, hashes_dev, cw);
@@ -33,7 +41,11 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
     const int m = c->cfg.m;
     const unsigned long long* guard = nullptr;
     unsigned long long guard_cap = 0;
-    const bool want_mfma = (c->encode_mode == 2) || (c->encode_mode == 0 && nq >= 4096);
+    // auto: the MFMA pre-filter pays from ~3e9 multiply-adds per call (its fixed part is the exact re-check of the pairs on a bucket
+    // edge, one serial chain of d terms each: ~0.23 us per dimension).  tools/encode_bench.py, exact vs MFMA: 1 024 x 256 x 128
+    // 12 / 43 us, 4 096 x 256 x 960 166 / 368 us, 8 192 x 1 024 x 768 765 / 531 us, 262 144 x 256 x 128 1 080 / 533 us.
+    const bool want_mfma = (c->encode_mode == 2) ||
+                           (c->encode_mode == 0 && static_cast<double>(nq) * c->P_total * c->cfg.dim >= 3.0e9);
     if (want_mfma && !proj_dev && c->d_alphaT32 && c->W <= 3) {      // (the fused bit-pack epilogue carries three code words: <= 192 bits)
         int rc = launch_encode_mfma<TIn>(c, nq, q_dev, codes_dev, hashes_dev, bad_dev);
         if (rc <= 0) return rc;  // error

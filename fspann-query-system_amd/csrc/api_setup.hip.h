@@ -296,6 +296,7 @@ int fspann_ctx_create(int device, const fspann_cfg* cfg, fspann_ctx** out) {
         c->knob_route_lds_kb = env_int("FSPANN_ROUTE_LDS_KB", 0);
         c->knob_zero_copy = env_int("FSPANN_ZERO_COPY", 1) != 0;
         c->knob_encode_qb = env_int("FSPANN_ENCODE_QB", 0);
+        c->knob_mfma_tile = env_int("FSPANN_ENCODE_MFMA_TILE", 0);
         c->knob_route_wgs = env_int("FSPANN_ROUTE_WGS", 0);
         c->knob_refine_run = env_int("FSPANN_REFINE_RUN", 1) != 0;
         c->knob_devflags = env_int("FSPANN_ROUTE_DEVFLAGS", 0);

@@ -246,21 +246,26 @@ namespace fspann {
 typedef float fsp_acc16 __attribute__((ext_vector_type(16)));
 typedef float fsp_f4 __attribute__((ext_vector_type(4)));
 constexpr int kMfmaKT = 32;        // K tile
-constexpr int kMfmaTileQ = 64;     // block tile: 64 queries ...
-constexpr int kMfmaTileP = 256;    // ... x 256 projections; wave w owns columns [64 w, 64 w + 64) = 2 x 2 MFMA tiles of 32 x 32
-constexpr int kMfmaTile = kMfmaTileQ;
+// Block tile = (32 RT) queries x (128 CT) projections, four waves; wave w owns columns [32 CT w, 32 CT (w + 1)) = RT x CT MFMA tiles
+// of 32 x 32.  RT = CT = 2 (64 x 256) for bulk coding — the index build, batches of thousands: the V tile is read once per 256
+// projections; RT = CT = 1 (32 x 128) for a query batch of a few hundred to a few thousand rows, where the large tile would leave
+// most CUs without a block (BASELINE config #3's shard: 512 queries x 256 projections = 8 blocks) and one wave would run 4 x 480
+// dependent MFMAs instead of 480.
+constexpr int mfma_tile_q(int RT) { return 32 * RT; }
+constexpr int mfma_tile_p(int CT) { return 128 * CT; }
 
 // One block = 64 vectors x 256 projections (the V tile is read once per 256 projections: with the old 64 x 64 tile every vector
 // row was fetched P / 64 times).  Epilogue: quantise (floor((y + r) / omega), Coding.java:254-255) AND bit-pack (Coding.C,
 // :285-301) in place — the bits of every pair whose fp32 result is provably on the right side of its bucket edges are OR-ed
 // straight into the (pre-zeroed) code words, one ballot per bit plane; the other pairs go to the fix list and encode_fix_kernel
 // ORs THEIR bits after the exact fp64 chain.  No int32 H round trip through HBM, no pack kernel (hashes != null: H is written too).
-template <typename TIn>
+template <typename TIn, int RT, int CT>
 __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
     const TIn* __restrict__ q, int64_t nq, int d, const float* __restrict__ alphaT32 /*[d][P]*/,
     const double* __restrict__ r, const double* __restrict__ omega, int P, int m, int lambda, int W, int TD, int32_t* __restrict__ hashes,
     unsigned long long* __restrict__ codes, int32_t* __restrict__ bad, int64_t* __restrict__ fix_list, int64_t fix_cap,
     unsigned long long* __restrict__ fix_count, double alpha_norm_max) {
+    constexpr int kMfmaTileQ = mfma_tile_q(RT), kMfmaTileP = mfma_tile_p(CT);
     __shared__ float Vs[kMfmaTileQ][kMfmaKT + 1];
     __shared__ __align__(16) float As[kMfmaKT][kMfmaTileP];
     __shared__ double rnorm2[kMfmaTileQ];
@@ -269,23 +274,25 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
     const int64_t q0 = static_cast<int64_t>(blockIdx.x) * kMfmaTileQ;
     const int p0 = blockIdx.y * kMfmaTileP;
     if (tid < kMfmaTileQ) { rnorm2[tid] = 0.0; badrow[tid] = 0; }
-    fsp_acc16 acc[2][2];
+    fsp_acc16 acc[RT][CT];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < RT; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < CT; b++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[a][b][i] = 0.0f;
-    double nrm[8];
+    constexpr int kVRows = kMfmaTileQ / 8;          // V rows per thread (thread t: column t & 31 of rows (t >> 5) + 8 i)
+    constexpr int kAVecs = kMfmaKT * kMfmaTileP / 4 / 256;   // 16-byte pieces of the A tile per thread
+    double nrm[kVRows];
 #pragma unroll
-    for (int i = 0; i < 8; i++) nrm[i] = 0.0;
+    for (int i = 0; i < kVRows; i++) nrm[i] = 0.0;
     __syncthreads();
     const bool a_vec = ((P & 3) == 0);
 
     for (int k0 = 0; k0 < d; k0 += kMfmaKT) {
-        // V tile: 64 rows x 32 k; thread t covers column t&31 of rows (t>>5) + 8 i
+        // V tile: kMfmaTileQ rows x 32 k; thread t covers column t&31 of rows (t>>5) + 8 i
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < kVRows; i++) {
             const int row = (tid >> 5) + 8 * i, col = tid & 31;
             const int64_t qi = q0 + row;
             double v = 0.0;
@@ -296,11 +303,11 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
             Vs[row][col] = static_cast<float>(v);
             nrm[i] += v * v;
         }
-        // A tile: 32 k x 256 projections (coalesced 16-byte pieces of alphaT32's rows)
+        // A tile: 32 k x kMfmaTileP projections (coalesced 16-byte pieces of alphaT32's rows)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < kAVecs; i++) {
             const int e = (tid + i * 256) * 4;
-            const int kk = e >> 8, pc = e & 255;
+            const int kk = e / kMfmaTileP, pc = e % kMfmaTileP;
             fsp_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
             if (k0 + kk < d) {
                 const float* src = alphaT32 + static_cast<int64_t>(k0 + kk) * P + p0 + pc;
@@ -315,18 +322,21 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < kMfmaKT; kk += 2) {
-            const float a0 = Vs[(lane & 31)][kk + (lane >> 5)], a1 = Vs[32 + (lane & 31)][kk + (lane >> 5)];
-            const float b0 = As[kk + (lane >> 5)][wave * 64 + (lane & 31)], b1 = As[kk + (lane >> 5)][wave * 64 + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[RT], bv[CT];
+#pragma unroll
+            for (int a = 0; a < RT; a++) av[a] = Vs[32 * a + (lane & 31)][kk + (lane >> 5)];
+#pragma unroll
+            for (int b = 0; b < CT; b++) bv[b] = As[kk + (lane >> 5)][wave * (32 * CT) + 32 * b + (lane & 31)];
+#pragma unroll
+            for (int a = 0; a < RT; a++)
+#pragma unroll
+                for (int b = 0; b < CT; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
     }
     // row norms: reduce the 32 lanes that share a row, one writer per row
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < kVRows; i++) {
         double s = nrm[i];
         for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
         if ((tid & 31) == 0) rnorm2[(tid >> 5) + 8 * i] = s;
@@ -340,8 +350,8 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
     __syncthreads();
     const int half = lane >> 5, c32 = lane & 31;
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) {
-        const int pb = p0 + wave * 64 + ct * 32;            // first projection of this 32-column tile (wave-uniform)
+    for (int ct = 0; ct < CT; ct++) {
+        const int pb = p0 + wave * (32 * CT) + ct * 32;     // first projection of this 32-column tile (wave-uniform)
         const int p = pb + c32;
         const double rr = (p < P) ? r[p] : 0.0, ww = (p < P) ? omega[p] : 1.0;
         // bucket guess through the reciprocal (a fp64 divide per pair was as long as the block's whole MFMA phase): ANY guess is
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
         const int j_lo = pb + c_lo - my_td * m;
         const unsigned fmask = (flen >= 32) ? 0xFFFFFFFFu : ((1u << max(flen, 0)) - 1u);
 #pragma unroll
-        for (int rt = 0; rt < 2; rt++) {
+        for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;

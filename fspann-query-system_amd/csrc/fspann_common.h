@@ -103,6 +103,7 @@ struct fspann_ctx {
     int knob_tick_front = 100;       // FSPANN_TICK_FRONT: percent of a tick's Route workgroups that head the grid
     int knob_bincheck = -1;          // FSPANN_ROUTE_BINCHECK: the bounded select's exact treeify check (-1: on for opaque ids, off for decimal ordinals; 0 / 1 force)
     bool knob_shape_spec = true;     // FSPANN_ROUTE_SHAPE_SPEC=0: the bounded select's build with run-time tables x probes also for 16 x 5 (dev A/B)
+    int knob_mfma_tile = 0;          // FSPANN_ENCODE_MFMA_TILE=1: the 32 x 128 block tile of the MFMA encode for every batch size (dev A/B)
     int knob_encode_qb = 0;          // FSPANN_ENCODE_QB: query rows per workgroup of the exact encode (0 = by batch size; dev A/B)
     bool knob_zero_copy = true;      // FSPANN_ZERO_COPY=0: tiny host-pointer calls go through copy commands like larger ones (dev A/B)
     int knob_route_lds_kb = 0;       // FSPANN_ROUTE_LDS_KB: LDS the full select may plan with (0 = all of it); less leaves room for scan workgroups beside it
