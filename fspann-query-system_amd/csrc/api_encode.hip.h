@@ -28,8 +28,10 @@ int launch_encode_mfma(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* co
                            c->cfg.lambda, c->W, c->TD, hashes_dev, cw, bad_dev, list, cap, cnt, c->alpha_norm_max);
     }
     FSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL((encode_fix_kernel<TIn>), dim3(static_cast<unsigned>(std::min<int64_t>(1024, (cap + 255) / 256))), dim3(256), 0, c->stream,
-                       q_dev, d, c->d_alphaT, c->d_r, c->d_omega, P, c->cfg.m, c->cfg.lambda, c->W, c->TD, list, cnt, cap, hashes_dev, cw);
+    // (a wave per kFixG pairs: as many blocks as the list can need, at most four per CU — the waves stride over the tasks)
+    const int64_t fix_blocks = std::min<int64_t>(static_cast<int64_t>(c->num_cus) * 4, (cap + kFixG * 4 - 1) / (kFixG * 4));
+    hipLaunchKernelGGL((encode_fix_kernel<TIn>), dim3(static_cast<unsigned>(std::max<int64_t>(1, fix_blocks))), dim3(256), 0, c->stream,
+                       q_dev, d, c->d_alpha_rows, c->d_r, c->d_omega, P, c->cfg.m, c->cfg.lambda, c->W, c->TD, list, cnt, cap, hashes_dev, cw);
     FSP_HIP(hipGetLastError());
     c->fix_cap_last = static_cast<unsigned long long>(cap);
     return 1;  // caller enqueues the exact kernel guarded by (count > cap): it only runs if the list overflowed
@@ -41,11 +43,11 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
     const int m = c->cfg.m;
     const unsigned long long* guard = nullptr;
     unsigned long long guard_cap = 0;
-    // auto: the MFMA pre-filter pays from ~3e9 multiply-adds per call (its fixed part is the exact re-check of the pairs on a bucket
-    // edge, one serial chain of d terms each: ~0.23 us per dimension).  tools/encode_bench.py, exact vs MFMA: 1 024 x 256 x 128
-    // 12 / 43 us, 4 096 x 256 x 960 166 / 368 us, 8 192 x 1 024 x 768 765 / 531 us, 262 144 x 256 x 128 1 080 / 533 us.
+    // auto: the MFMA pre-filter pays from ~5e8 multiply-adds per call (its fixed part: clearing the code words, the exact re-check of the
+    // pairs on a bucket edge, four launches).  tools/encode_bench.py, exact vs MFMA: 1 024 x 256 x 128 12 / 31 us, 512 x 256 x 960
+    // 48 / 84, 1 024 x 1 024 x 768 132 / 94, 4 096 x 256 x 960 169 / 113, 8 192 x 1 024 x 768 758 / 288, 262 144 x 256 x 128 1 080 / 502.
     const bool want_mfma = (c->encode_mode == 2) ||
-                           (c->encode_mode == 0 && static_cast<double>(nq) * c->P_total * c->cfg.dim >= 3.0e9);
+                           (c->encode_mode == 0 && static_cast<double>(nq) * c->P_total * c->cfg.dim >= 5.0e8);
     if (want_mfma && !proj_dev && c->d_alphaT32 && c->W <= 3) {      // (the fused bit-pack epilogue carries three code words: <= 192 bits)
         int rc = launch_encode_mfma<TIn>(c, nq, q_dev, codes_dev, hashes_dev, bad_dev);
         if (rc <= 0) return rc;  // error

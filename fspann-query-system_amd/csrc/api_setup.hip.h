@@ -341,12 +341,12 @@ void fspann_ctx_destroy(fspann_ctx* c) {
         }
     }
     if (parent) {                                   // a clone owns none of the shared arrays
-        c->d_alphaT = nullptr; c->d_r = nullptr; c->d_omega = nullptr; c->d_alphaT32 = nullptr;
+        c->d_alphaT = nullptr; c->d_r = nullptr; c->d_omega = nullptr; c->d_alphaT32 = nullptr; c->d_alpha_rows = nullptr;
         c->d_tables = nullptr; c->d_recs = nullptr; c->d_ids = nullptr; c->d_dir = nullptr; c->d_inv = nullptr; c->d_ids_bk = nullptr; c->d_bin16 = nullptr;
         c->d_java_hash = nullptr; c->d_deleted_bits = nullptr;
         if (!c->store_owned) c->d_store = nullptr;
     }
-    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_dev(c->ws_fix.p);
+    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_devt(c->d_alpha_rows); free_dev(c->ws_fix.p);
     free_devt(c->d_tables); free_devt(c->d_recs); free_devt(c->d_ids); free_devt(c->d_dir);
     free_devt(c->d_java_hash); free_devt(c->d_unmodelled);
     if (uint32_t* db = c->d_deleted_bits.exchange(nullptr)) (void)hipFree(db);
@@ -382,7 +382,7 @@ int fspann_ctx_clone(fspann_ctx* src, fspann_ctx** out) {
     if (rc) return rc;
     c->have_g = root->have_g; c->alpha_norm_max = root->alpha_norm_max; c->encode_mode = src->encode_mode;
     c->h_alpha = root->h_alpha; c->h_r = root->h_r; c->h_omega = root->h_omega;
-    c->d_alphaT = root->d_alphaT; c->d_r = root->d_r; c->d_omega = root->d_omega; c->d_alphaT32 = root->d_alphaT32;
+    c->d_alphaT = root->d_alphaT; c->d_r = root->d_r; c->d_omega = root->d_omega; c->d_alphaT32 = root->d_alphaT32; c->d_alpha_rows = root->d_alpha_rows;
     c->h_tables = root->h_tables;
     c->h_table_set.assign(c->TD, 1);
     c->d_tables = root->d_tables; c->d_recs = root->d_recs; c->rec_words = root->rec_words; c->d_dir = root->d_dir; c->dir_bits = root->dir_bits;
@@ -418,7 +418,7 @@ int fspann_set_gfunctions(fspann_ctx* c, const double* alpha, const double* r, c
     std::vector<double> aT(static_cast<size_t>(d) * P);
     for (int p = 0; p < P; p++)
         for (int i = 0; i < d; i++) aT[static_cast<size_t>(i) * P + p] = alpha[static_cast<size_t>(p) * d + i];
-    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32);
+    free_devt(c->d_alphaT); free_devt(c->d_r); free_devt(c->d_omega); free_devt(c->d_alphaT32); free_devt(c->d_alpha_rows);
     {
         std::vector<float> aT32(aT.size());
         for (size_t i = 0; i < aT.size(); i++) aT32[i] = static_cast<float>(aT[i]);
@@ -436,6 +436,8 @@ int fspann_set_gfunctions(fspann_ctx* c, const double* alpha, const double* r, c
     FSP_HIP(hipMalloc(&c->d_r, static_cast<size_t>(P) * 8));
     FSP_HIP(hipMalloc(&c->d_omega, static_cast<size_t>(P) * 8));
     FSP_HIP(hipMemcpy(c->d_alphaT, aT.data(), aT.size() * 8, hipMemcpyHostToDevice));
+    FSP_HIP(hipMalloc(&c->d_alpha_rows, aT.size() * 8));
+    FSP_HIP(hipMemcpy(c->d_alpha_rows, alpha, aT.size() * 8, hipMemcpyHostToDevice));
     FSP_HIP(hipMemcpy(c->d_r, r, static_cast<size_t>(P) * 8, hipMemcpyHostToDevice));
     FSP_HIP(hipMemcpy(c->d_omega, omega, static_cast<size_t>(P) * 8, hipMemcpyHostToDevice));
     if (c->h_alpha.data() != alpha) { c->h_alpha.assign(alpha, alpha + static_cast<size_t>(P) * d); c->h_r.assign(r, r + P); c->h_omega.assign(omega, omega + P); }

@@ -289,21 +289,18 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
     __syncthreads();
     const bool a_vec = ((P & 3) == 0);
 
-    for (int k0 = 0; k0 < d; k0 += kMfmaKT) {
-        // V tile: kMfmaTileQ rows x 32 k; thread t covers column t&31 of rows (t>>5) + 8 i
+    // The k loop keeps ONE tile ahead in registers: the global loads of tile k0 + 32 are requested before tile k0's MFMAs run and are
+    // written to LDS behind them.  (Loaded and used inside the same trip, a block waited for a round trip to memory per tile — with
+    // one or two blocks per CU nothing else hides it: 24-30 tiles x ~2.5 us = 65-100 us for a 512-1 024 row batch at d = 768 / 960.)
+    double vreg[kVRows];                    // this thread's V elements of the tile in flight (widened; 0 outside the batch / d)
+    fsp_f4 areg[kAVecs];
+    auto fetch = [&](const int k0) {
 #pragma unroll
         for (int i = 0; i < kVRows; i++) {
             const int row = (tid >> 5) + 8 * i, col = tid & 31;
             const int64_t qi = q0 + row;
-            double v = 0.0;
-            if (qi < nq && k0 + col < d) {
-                v = static_cast<double>(q[qi * d + k0 + col]);
-                if (!(fabs(v) <= 1.79769313486231570815e+308)) badrow[row] = 1;
-            }
-            Vs[row][col] = static_cast<float>(v);
-            nrm[i] += v * v;
+            vreg[i] = (qi < nq && k0 + col < d) ? static_cast<double>(q[qi * d + k0 + col]) : 0.0;
         }
-        // A tile: 32 k x kMfmaTileP projections (coalesced 16-byte pieces of alphaT32's rows)
 #pragma unroll
         for (int i = 0; i < kAVecs; i++) {
             const int e = (tid + i * 256) * 4;
@@ -317,9 +314,60 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
                     for (int u = 0; u < 4; u++) if (p0 + pc + u < P) a[u] = src[u];
                 }
             }
-            *reinterpret_cast<fsp_f4*>(&As[kk][pc]) = a;
+            areg[i] = a;
+        }
+    };
+    // (only the small tile: with the bulk tile the extra 40 registers cost the second block per CU — 502 -> 609 us per 262 144 rows —,
+    // and its blocks hide each other's loads anyway)
+    constexpr bool kAhead = (RT == 1 && CT == 1);
+    if constexpr (kAhead) fetch(0);
+    for (int k0 = 0; k0 < d; k0 += kMfmaKT) {
+        // V tile: kMfmaTileQ rows x 32 k (thread t: column t&31 of rows (t>>5) + 8 i); A tile: 32 k x kMfmaTileP projections
+        if constexpr (kAhead) {
+#pragma unroll
+            for (int i = 0; i < kVRows; i++) {
+                const int row = (tid >> 5) + 8 * i, col = tid & 31;
+                const double v = vreg[i];
+                if (!(fabs(v) <= 1.79769313486231570815e+308)) badrow[row] = 1;
+                Vs[row][col] = static_cast<float>(v);
+                nrm[i] += v * v;
+            }
+#pragma unroll
+            for (int i = 0; i < kAVecs; i++) {
+                const int e = (tid + i * 256) * 4;
+                *reinterpret_cast<fsp_f4*>(&As[e / kMfmaTileP][e % kMfmaTileP]) = areg[i];
+            }
+        } else {                                   // bulk tile: straight from memory into LDS, trip by trip
+#pragma unroll
+            for (int i = 0; i < kVRows; i++) {
+                const int row = (tid >> 5) + 8 * i, col = tid & 31;
+                const int64_t qi = q0 + row;
+                double v = 0.0;
+                if (qi < nq && k0 + col < d) {
+                    v = static_cast<double>(q[qi * d + k0 + col]);
+                    if (!(fabs(v) <= 1.79769313486231570815e+308)) badrow[row] = 1;
+                }
+                Vs[row][col] = static_cast<float>(v);
+                nrm[i] += v * v;
+            }
+#pragma unroll
+            for (int i = 0; i < kAVecs; i++) {
+                const int e = (tid + i * 256) * 4;
+                const int kk = e / kMfmaTileP, pc = e % kMfmaTileP;
+                fsp_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (k0 + kk < d) {
+                    const float* src = alphaT32 + static_cast<int64_t>(k0 + kk) * P + p0 + pc;
+                    if (a_vec && p0 + pc + 3 < P) a = *reinterpret_cast<const fsp_f4*>(src);
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (p0 + pc + u < P) a[u] = src[u];
+                    }
+                }
+                *reinterpret_cast<fsp_f4*>(&As[kk][pc]) = a;
+            }
         }
         __syncthreads();
+        if constexpr (kAhead) { if (k0 + kMfmaKT < d) fetch(k0 + kMfmaKT); }          // uniform; in flight while the MFMAs below run
 #pragma unroll
         for (int kk = 0; kk < kMfmaKT; kk += 2) {
             float av[RT], bv[CT];
@@ -415,36 +463,85 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
     }
 }
 
-// exact re-computation of the flagged (query, projection) pairs: one lane per pair, the reference's chain; the pair's code
-// bits are OR-ed into the code words (the MFMA epilogue left them clear).
+// Exact re-computation of the flagged (query, projection) pairs — the reference's chain, acc = acc + v[k] * alpha[k] for k = 0 .. d - 1
+// in that order (Coding.java:349-353) — and the pair's code bits OR-ed into the code words (the MFMA epilogue left them clear).
+// A wave takes kFixG pairs at a time: for every 64 dimensions, the 64 lanes compute one pair's 64 PRODUCTS at once (the query row and
+// the projection's row of alpha are both contiguous: two coalesced loads per pair and step) and park them in LDS; then lane g adds
+// pair g's 64 products to its running sum IN ORDER.  The products are the same fp64 roundings whoever computes them, the additions
+// keep their order: bit-identical to one lane walking the pair alone — which is what this kernel did, one lane per pair and two
+// scattered loads per dimension: 220 us for a few hundred pairs at d = 768 / 960 whatever the batch (the MFMA path's fixed cost).
+constexpr int kFixG = 8;            // pairs per wave task
+constexpr int kFixCH = 4;           // 64-dimension steps per chunk: 8 x 4 x 2 = 64 loads in flight per lane and round trip to memory
 template <typename TIn>
-__global__ __launch_bounds__(256) void encode_fix_kernel(const TIn* __restrict__ q, int d, const double* __restrict__ alphaT,
+__global__ __launch_bounds__(256) void encode_fix_kernel(const TIn* __restrict__ q, int d, const double* __restrict__ alpha_rows /*[P][d]*/,
                                                          const double* __restrict__ r, const double* __restrict__ omega, int P, int m, int lambda, int W, int TD,
                                                          const int64_t* __restrict__ fix_list, const unsigned long long* __restrict__ fix_count,
                                                          int64_t fix_cap, int32_t* __restrict__ hashes, unsigned long long* __restrict__ codes) {
+    constexpr int kChunk = 64 * kFixCH;
+    __shared__ double prods[256 / 64][kFixG][kChunk + 1];      // (+1: lane g reads row g — rows a multiple of 64 doubles apart would share a bank)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long n = min(*fix_count, static_cast<unsigned long long>(fix_cap));
-    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
-         i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
-        const int64_t e = fix_list[i];
-        const int64_t qi = e / P;
-        const int p = static_cast<int>(e - qi * P);
-        const TIn* v = q + qi * d;
-        double acc = 0.0;
-        for (int k = 0; k < d; k++) {
-            const double prod = static_cast<double>(v[k]) * alphaT[static_cast<int64_t>(k) * P + p];
-            acc = acc + prod;
+    const unsigned long long ntasks = (n + kFixG - 1) / kFixG;
+    const unsigned long long nwaves = static_cast<unsigned long long>(gridDim.x) * (blockDim.x >> 6);
+    for (unsigned long long task = static_cast<unsigned long long>(blockIdx.x) * (blockDim.x >> 6) + wave; task < ntasks; task += nwaves) {   // wave-uniform
+        const unsigned long long i = task * kFixG + lane;
+        const bool mine = lane < kFixG && i < n;
+        const int64_t e = mine ? fix_list[i] : -1;
+        const int64_t qi = mine ? e / P : 0;
+        const int p = mine ? static_cast<int>(e - qi * P) : 0;
+        // every pair's row bases once per task (a pair past the end of the list re-reads pair 0's rows: computed, never used)
+        const TIn* qrow[kFixG];
+        const double* arow[kFixG];
+#pragma unroll
+        for (int g = 0; g < kFixG; g++) {
+            qrow[g] = q + __shfl(qi, g) * d;
+            arow[g] = alpha_rows + static_cast<int64_t>(__shfl(p, g)) * d;
         }
-        const double y = acc + r[p];
-        const int32_t h = java_d2i(floor(y / omega[p]));
-        if (hashes) hashes[e] = h;
-        const uint32_t hj = static_cast<uint32_t>(h) ^ 0x80000000u;
-        const int td = p / m, j = p - td * m;
-        unsigned long long* cw = codes + (qi * TD + td) * W;
-        for (int b = 0; b < lambda; b++)
-            if ((hj >> (b & 31)) & 1u) {
-                const int pos = (lambda - 1 - b) * m + j;
-                atomicOr(cw + (pos >> 6), 1ull << (pos & 63));
+        double acc = 0.0;
+        for (int k0 = 0; k0 < d; k0 += kChunk) {
+            double pr[kFixG][kFixCH];
+#pragma unroll
+            for (int g = 0; g < kFixG; g++)
+#pragma unroll
+                for (int c = 0; c < kFixCH; c++) {
+                    const int k = min(k0 + c * 64 + lane, d - 1);           // (clamped: a product past d is never added)
+                    pr[g][c] = static_cast<double>(qrow[g][k]) * arow[g][k];
+                }
+#pragma unroll
+            for (int g = 0; g < kFixG; g++)
+#pragma unroll
+                for (int c = 0; c < kFixCH; c++) prods[wave][g][c * 64 + lane] = pr[g][c];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                const int kn = min(kChunk, d - k0);
+                const double* mine_row = prods[wave][lane];
+                int j = 0;
+                for (; j + 8 <= kn; j += 8) {                // eight LDS reads requested together, then added IN ORDER (Coding.java:351): one
+                    double t[8];                              //   read latency per eight terms instead of one per term
+#pragma unroll
+                    for (int u = 0; u < 8; u++) t[u] = mine_row[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc = acc + t[u];
+                }
+                for (; j < kn; j++) acc = acc + mine_row[j];
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (mine) {
+            const double y = acc + r[p];
+            const int32_t h = java_d2i(floor(y / omega[p]));
+            if (hashes) hashes[e] = h;
+            const uint32_t hj = static_cast<uint32_t>(h) ^ 0x80000000u;
+            const int td = p / m, j = p - td * m;
+            unsigned long long* cw = codes + (qi * TD + td) * W;
+            for (int b = 0; b < lambda; b++)
+                if ((hj >> (b & 31)) & 1u) {
+                    const int pos = (lambda - 1 - b) * m + j;
+                    atomicOr(cw + (pos >> 6), 1ull << (pos & 63));
+                }
+        }
     }
 }
 

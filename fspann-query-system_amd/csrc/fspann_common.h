@@ -115,6 +115,7 @@ struct fspann_ctx {
 
     // GFunctions: alphaT[dim][P_total] fp64 (transposed for coalescing), r/omega[P_total]
     double* d_alphaT = nullptr;
+    double* d_alpha_rows = nullptr;   // alpha as the JVM hands it over, [P][d]: the re-check of the MFMA path reads a projection's row 64 dimensions at a time
     double* d_r = nullptr;
     double* d_omega = nullptr;
     std::vector<double> h_alpha, h_r, h_omega;  // host copies (export)

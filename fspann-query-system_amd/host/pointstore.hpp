@@ -470,7 +470,6 @@ inline void pointstore_open_batch(fspann_pointstore* ps, int64_t nq, int64_t B, 
         if (!state[wi]) state[wi].reset(new PerThread(a, dim));
         GcmWorker& w = state[wi]->w;
         std::vector<unsigned char>& scratch = state[wi]->scratch;
-        std::vector<double>& row = state[wi]->row;
         long long okc = 0, badc = 0;
         for (int64_t q = qb; q < qe; q++) {
             const int c = std::max(0, std::min<int>(count[q], static_cast<int>(B)));

@@ -97,14 +97,14 @@ def test_mfma_nonfinite_and_huge(pkg, oracle):
 
 
 def test_auto_mode_index_build_uses_mfma_and_matches(pkg, oracle):
-    T, D, m, lam, d, n = 4, 1, 16, 2, 256, 200000      # 200 000 x 64 x 256 = 3.3e9 multiply-adds: above the auto rule's 3e9
+    T, D, m, lam, d, n = 4, 1, 16, 2, 256, 200000      # 200 000 x 64 x 256 = 3.3e9 multiply-adds: above the auto rule's 5e8
     rng, o, ctx, _ = _setup(pkg, oracle, T, D, m, lam, d, seed=8)
     X = rng.standard_normal((n, d)).astype(np.float32)
     o.set_id_meta(n)
     o.build_index(X.astype(np.float64))
     with ctx:
         ctx.set_id_meta(n)
-        ctx.build_index(X)                      # auto mode: rows x projections x dim >= 3e9 -> MFMA path
+        ctx.build_index(X)                      # auto mode: rows x projections x dim >= 5e8 -> MFMA path
         assert ctx.last_encode_rechecked() > 0   # (only the MFMA path re-checks pairs)
         for td in range(T * D):
             a, b = ctx.get_index(td), o.get_index(td)
