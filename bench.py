@@ -761,7 +761,7 @@ def main():
                 rows=Q, exact_fp64_valu=q_enc["exact"], mfma_prefilter_plus_recheck=q_enc["mfma"], pairs=Q * TD * m, codes_equal=True,
                 shipped="exact" if q_enc["exact"]["us_per_call"] <= q_enc["mfma"]["us_per_call"] else "exact (inside front_kernel)",
                 note="whole fspann_encode_dev calls back to back on one stream (mode 2 = clear of the code words + encode_mfma_kernel + "
-                     "encode_fix_kernel: three dependent launches); at Q rows the 64 x 256 MFMA tile yields Q/64 workgroups for 256 CUs, "
+                     "encode_fix_kernel: three dependent launches; 32 x 128 block tile at this size, one MFMA tile per wave); the path wins from ~5e8 multiply-adds per call, "
                      "and in the default pipeline the exact kernel's workgroups ride inside front_kernel beside Route's, where they are off "
                      "the critical path (DESIGN.md §3.1)"),
             query_side=dict(kernel="encode_exact_kernel<float,4> (its workgroups ride inside front_kernel in the default pipeline)", rows=Q,
