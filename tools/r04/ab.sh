@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev A/B on one box: bench.py at a workload against variant libraries.  usage: tools/r04_ab.sh <outdir> <workload args...> -- name=lib[:ENV=..] ...
+# dev A/B on one box: bench.py at a workload against variant libraries.  usage: tools/r04/ab.sh <outdir> <workload args...> -- name=lib[:ENV=..] ...
 set -o pipefail
 out=gpurun_out/$1; shift; mkdir -p $out
 args=()
