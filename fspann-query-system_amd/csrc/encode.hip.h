@@ -251,6 +251,9 @@ constexpr int kMfmaKT = 32;        // K tile
 // projections; RT = CT = 1 (32 x 128) for a query batch of a few hundred to a few thousand rows, where the large tile would leave
 // most CUs without a block (BASELINE config #3's shard: 512 queries x 256 projections = 8 blocks) and one wave would run 4 x 480
 // dependent MFMAs instead of 480.
+// Workgroup barrier that waits for THIS wave's LDS traffic only.  __syncthreads() also waits for every outstanding global load
+// (s_waitcnt vmcnt(0) in front of s_barrier), which is exactly what a k loop with the next tile's loads in flight must not do.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int mfma_tile_q(int RT) { return 32 * RT; }
 constexpr int mfma_tile_p(int CT) { return 128 * CT; }
 
@@ -294,27 +297,31 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
     // one or two blocks per CU nothing else hides it: 24-30 tiles x ~2.5 us = 65-100 us for a 512-1 024 row batch at d = 768 / 960.)
     double vreg[kVRows];                    // this thread's V elements of the tile in flight (widened; 0 outside the batch / d)
     fsp_f4 areg[kAVecs];
+    // Every load of the tile in flight is UNCONDITIONAL (an element outside the batch, d or P is read from a clamped address and replaced
+    // by zero when the tile is written to LDS): behind a branch the compiler waits for each load before it issues the next (the ISA had a
+    // `s_waitcnt vmcnt(0)` behind every guarded load), and the loop's barriers wait for LDS only (lds_barrier) — __syncthreads would
+    // wait for the tile in flight at the end of every trip.
     auto fetch = [&](const int k0) {
 #pragma unroll
         for (int i = 0; i < kVRows; i++) {
             const int row = (tid >> 5) + 8 * i, col = tid & 31;
-            const int64_t qi = q0 + row;
-            vreg[i] = (qi < nq && k0 + col < d) ? static_cast<double>(q[qi * d + k0 + col]) : 0.0;
+            vreg[i] = static_cast<double>(q[min(q0 + row, nq - 1) * d + min(k0 + col, d - 1)]);
         }
 #pragma unroll
         for (int i = 0; i < kAVecs; i++) {
             const int e = (tid + i * 256) * 4;
             const int kk = e / kMfmaTileP, pc = e % kMfmaTileP;
-            fsp_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (k0 + kk < d) {
-                const float* src = alphaT32 + static_cast<int64_t>(k0 + kk) * P + p0 + pc;
-                if (a_vec && p0 + pc + 3 < P) a = *reinterpret_cast<const fsp_f4*>(src);
-                else {
+            if (a_vec) {                               // uniform: P % 4 == 0, so a 16-byte piece lies wholly inside or wholly outside P
+                areg[i] = *reinterpret_cast<const fsp_f4*>(alphaT32 + static_cast<int64_t>(min(k0 + kk, d - 1)) * P + min(p0 + pc, P - 4));
+            } else {
+                fsp_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (k0 + kk < d) {
+                    const float* src = alphaT32 + static_cast<int64_t>(k0 + kk) * P + p0 + pc;
 #pragma unroll
                     for (int u = 0; u < 4; u++) if (p0 + pc + u < P) a[u] = src[u];
                 }
+                areg[i] = a;
             }
-            areg[i] = a;
         }
     };
     // (only the small tile: with the bulk tile the extra 40 registers cost the second block per CU — 502 -> 609 us per 262 144 rows —,
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
 #pragma unroll
             for (int i = 0; i < kVRows; i++) {
                 const int row = (tid >> 5) + 8 * i, col = tid & 31;
-                const double v = vreg[i];
+                const double v = (q0 + row < nq && k0 + col < d) ? vreg[i] : 0.0;
                 if (!(fabs(v) <= 1.79769313486231570815e+308)) badrow[row] = 1;
                 Vs[row][col] = static_cast<float>(v);
                 nrm[i] += v * v;
@@ -335,7 +342,9 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
 #pragma unroll
             for (int i = 0; i < kAVecs; i++) {
                 const int e = (tid + i * 256) * 4;
-                *reinterpret_cast<fsp_f4*>(&As[e / kMfmaTileP][e % kMfmaTileP]) = areg[i];
+                const int kk = e / kMfmaTileP, pc = e % kMfmaTileP;
+                const fsp_f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                *reinterpret_cast<fsp_f4*>(&As[kk][pc]) = (!a_vec || (k0 + kk < d && p0 + pc < P)) ? areg[i] : zero;
             }
         } else {                                   // bulk tile: straight from memory into LDS, trip by trip
 #pragma unroll
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
                 *reinterpret_cast<fsp_f4*>(&As[kk][pc]) = a;
             }
         }
-        __syncthreads();
+        if constexpr (kAhead) lds_barrier(); else __syncthreads();
         if constexpr (kAhead) { if (k0 + kMfmaKT < d) fetch(k0 + kMfmaKT); }          // uniform; in flight while the MFMAs below run
 #pragma unroll
         for (int kk = 0; kk < kMfmaKT; kk += 2) {
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
 #pragma unroll
                 for (int b = 0; b < CT; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();
+        if constexpr (kAhead) lds_barrier(); else __syncthreads();
     }
     // row norms: reduce the 32 lanes that share a row, one writer per row
 #pragma unroll
