@@ -10,6 +10,7 @@
 // wave reads 64 consecutive doubles per dimension (512 B, coalesced); the QB query
 // vectors of a block sit in LDS and are broadcast to all lanes.
 #pragma once
+#include <type_traits>
 #include "fspann_common.h"
 
 #pragma clang fp contract(off)
@@ -292,49 +293,63 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
     __syncthreads();
     const bool a_vec = ((P & 3) == 0);
 
-    // The k loop keeps ONE tile ahead in registers: the global loads of tile k0 + 32 are requested before tile k0's MFMAs run and are
-    // written to LDS behind them.  (Loaded and used inside the same trip, a block waited for a round trip to memory per tile — with
-    // one or two blocks per CU nothing else hides it: 24-30 tiles x ~2.5 us = 65-100 us for a 512-1 024 row batch at d = 768 / 960.)
-    double vreg[kVRows];                    // this thread's V elements of the tile in flight (widened; 0 outside the batch / d)
-    fsp_f4 areg[kAVecs];
-    // Every load of the tile in flight is UNCONDITIONAL (an element outside the batch, d or P is read from a clamped address and replaced
-    // by zero when the tile is written to LDS): behind a branch the compiler waits for each load before it issues the next (the ISA had a
-    // `s_waitcnt vmcnt(0)` behind every guarded load), and the loop's barriers wait for LDS only (lds_barrier) — __syncthreads would
-    // wait for the tile in flight at the end of every trip.
-    auto fetch = [&](const int k0) {
+    auto mfma_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < kVRows; i++) {
-            const int row = (tid >> 5) + 8 * i, col = tid & 31;
-            vreg[i] = static_cast<double>(q[min(q0 + row, nq - 1) * d + min(k0 + col, d - 1)]);
-        }
+        for (int kk = 0; kk < kMfmaKT; kk += 2) {
+            float av[RT], bv[CT];
 #pragma unroll
-        for (int i = 0; i < kAVecs; i++) {
-            const int e = (tid + i * 256) * 4;
-            const int kk = e / kMfmaTileP, pc = e % kMfmaTileP;
-            if (a_vec) {                               // uniform: P % 4 == 0, so a 16-byte piece lies wholly inside or wholly outside P
-                areg[i] = *reinterpret_cast<const fsp_f4*>(alphaT32 + static_cast<int64_t>(min(k0 + kk, d - 1)) * P + min(p0 + pc, P - 4));
-            } else {
-                fsp_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (k0 + kk < d) {
-                    const float* src = alphaT32 + static_cast<int64_t>(k0 + kk) * P + p0 + pc;
+            for (int a = 0; a < RT; a++) av[a] = Vs[32 * a + (lane & 31)][kk + (lane >> 5)];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) if (p0 + pc + u < P) a[u] = src[u];
-                }
-                areg[i] = a;
-            }
+            for (int b = 0; b < CT; b++) bv[b] = As[kk + (lane >> 5)][wave * (32 * CT) + 32 * b + (lane & 31)];
+#pragma unroll
+            for (int a = 0; a < RT; a++)
+#pragma unroll
+                for (int b = 0; b < CT; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
     };
-    // (only the small tile: with the bulk tile the extra 40 registers cost the second block per CU — 502 -> 609 us per 262 144 rows —,
-    // and its blocks hide each other's loads anyway)
     constexpr bool kAhead = (RT == 1 && CT == 1);
-    if constexpr (kAhead) fetch(0);
-    for (int k0 = 0; k0 < d; k0 += kMfmaKT) {
-        // V tile: kMfmaTileQ rows x 32 k (thread t: column t&31 of rows (t>>5) + 8 i); A tile: 32 k x kMfmaTileP projections
-        if constexpr (kAhead) {
+    if constexpr (kAhead) {
+        // Small tile: kSets register sets in rotation keep the NEXT kSets - 1 tiles in flight: a set is written to LDS, refilled with the
+        // tile kSets ahead, and its tile multiplied.  (Loaded and used inside the same trip, a block waited for a round trip to memory per
+        // tile — with one block per CU nothing else hides it: 24-30 tiles x ~2.5 us = 65-100 us for a 512-1 024 row batch at d = 768 /
+        // 960; a tile's 16 MFMAs are ~0.5 us, so one tile ahead is not enough.)
+        // Every load is UNCONDITIONAL (an element outside the batch, d or P is read from a clamped address and replaced by zero when the
+        // tile is written to LDS): behind a branch the compiler waits for each load before it issues the next (the ISA had a
+        // `s_waitcnt vmcnt(0)` behind every guarded load); and the loop's barriers wait for LDS only (lds_barrier) — __syncthreads would
+        // wait for the tiles in flight at the end of every trip.
+        constexpr int kSets = 3;
+        double vreg[kSets][kVRows];
+        fsp_f4 areg[kSets][kAVecs];
+        auto fetch = [&](auto set_c, const int k0) {
+            constexpr int st = decltype(set_c)::value;
 #pragma unroll
             for (int i = 0; i < kVRows; i++) {
                 const int row = (tid >> 5) + 8 * i, col = tid & 31;
-                const double v = (q0 + row < nq && k0 + col < d) ? vreg[i] : 0.0;
+                vreg[st][i] = static_cast<double>(q[min(q0 + row, nq - 1) * d + min(k0 + col, d - 1)]);
+            }
+#pragma unroll
+            for (int i = 0; i < kAVecs; i++) {
+                const int e = (tid + i * 256) * 4;
+                const int kk = e / kMfmaTileP, pc = e % kMfmaTileP;
+                if (a_vec) {                           // uniform: P % 4 == 0, so a 16-byte piece lies wholly inside or wholly outside P
+                    areg[st][i] = *reinterpret_cast<const fsp_f4*>(alphaT32 + static_cast<int64_t>(min(k0 + kk, d - 1)) * P + min(p0 + pc, P - 4));
+                } else {
+                    fsp_f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (k0 + kk < d) {
+                        const float* src = alphaT32 + static_cast<int64_t>(k0 + kk) * P + p0 + pc;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (p0 + pc + u < P) a[u] = src[u];
+                    }
+                    areg[st][i] = a;
+                }
+            }
+        };
+        auto tile_from = [&](auto set_c, const int k0) {
+            constexpr int st = decltype(set_c)::value;
+#pragma unroll
+            for (int i = 0; i < kVRows; i++) {
+                const int row = (tid >> 5) + 8 * i, col = tid & 31;
+                const double v = (q0 + row < nq && k0 + col < d) ? vreg[st][i] : 0.0;
                 if (!(fabs(v) <= 1.79769313486231570815e+308)) badrow[row] = 1;
                 Vs[row][col] = static_cast<float>(v);
                 nrm[i] += v * v;
@@ -344,9 +359,27 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
                 const int e = (tid + i * 256) * 4;
                 const int kk = e / kMfmaTileP, pc = e % kMfmaTileP;
                 const fsp_f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-                *reinterpret_cast<fsp_f4*>(&As[kk][pc]) = (!a_vec || (k0 + kk < d && p0 + pc < P)) ? areg[i] : zero;
+                *reinterpret_cast<fsp_f4*>(&As[kk][pc]) = (!a_vec || (k0 + kk < d && p0 + pc < P)) ? areg[st][i] : zero;
             }
-        } else {                                   // bulk tile: straight from memory into LDS, trip by trip
+            lds_barrier();
+            if (k0 + kSets * kMfmaKT < d) fetch(set_c, k0 + kSets * kMfmaKT);      // uniform: the set just emptied takes the tile kSets ahead
+            mfma_tile();
+            lds_barrier();
+        };
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+        fetch(S0{}, 0);
+        if (kMfmaKT < d) fetch(S1{}, kMfmaKT);
+        if (2 * kMfmaKT < d) fetch(S2{}, 2 * kMfmaKT);
+        for (int k0 = 0; k0 < d; k0 += kSets * kMfmaKT) {                           // uniform trips
+            tile_from(S0{}, k0);
+            if (k0 + kMfmaKT < d) tile_from(S1{}, k0 + kMfmaKT);
+            if (k0 + 2 * kMfmaKT < d) tile_from(S2{}, k0 + 2 * kMfmaKT);
+        }
+    } else {
+        // Bulk tile: straight from memory into LDS, trip by trip — its blocks hide each other's loads, and registers for a tile in flight
+        // cost it the second block per CU (502 -> 609 us per 262 144 rows).
+        for (int k0 = 0; k0 < d; k0 += kMfmaKT) {
+            // V tile: kMfmaTileQ rows x 32 k (thread t: column t&31 of rows (t>>5) + 8 i); A tile: 32 k x kMfmaTileP projections
 #pragma unroll
             for (int i = 0; i < kVRows; i++) {
                 const int row = (tid >> 5) + 8 * i, col = tid & 31;
@@ -374,22 +407,10 @@ __global__ __launch_bounds__(256, 2) void encode_mfma_kernel(
                 }
                 *reinterpret_cast<fsp_f4*>(&As[kk][pc]) = a;
             }
+            __syncthreads();
+            mfma_tile();
+            __syncthreads();
         }
-        if constexpr (kAhead) lds_barrier(); else __syncthreads();
-        if constexpr (kAhead) { if (k0 + kMfmaKT < d) fetch(k0 + kMfmaKT); }          // uniform; in flight while the MFMAs below run
-#pragma unroll
-        for (int kk = 0; kk < kMfmaKT; kk += 2) {
-            float av[RT], bv[CT];
-#pragma unroll
-            for (int a = 0; a < RT; a++) av[a] = Vs[32 * a + (lane & 31)][kk + (lane >> 5)];
-#pragma unroll
-            for (int b = 0; b < CT; b++) bv[b] = As[kk + (lane >> 5)][wave * (32 * CT) + 32 * b + (lane & 31)];
-#pragma unroll
-            for (int a = 0; a < RT; a++)
-#pragma unroll
-                for (int b = 0; b < CT; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-        }
-        if constexpr (kAhead) lds_barrier(); else __syncthreads();
     }
     // row norms: reduce the 32 lanes that share a row, one writer per row
 #pragma unroll
