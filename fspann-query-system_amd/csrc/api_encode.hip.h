@@ -16,9 +16,10 @@ int launch_encode_mfma(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* co
     // the code words start clear: the MFMA epilogue ORs in the bits of the pairs it can decide, encode_fix_kernel those of the rest
     FSP_HIP(hipMemsetAsync(codes_dev, 0, static_cast<size_t>(nq) * c->TD * c->W * 8, c->stream));
     unsigned long long* cw = reinterpret_cast<unsigned long long*>(codes_dev);
-    // block tile: 64 x 256 for bulk coding; 32 x 128 when that would not give every CU two blocks (query batches)
+    // block tile: 64 x 256 for bulk coding (Setup: hundreds of thousands of rows per call); 32 x 128 with tiles in flight for batches
+    // of up to a few thousand blocks of the large tile (8 192 x 1 024 x 768: 273 against 327 us; equal at 262 144 rows)
     const int64_t big_blocks = ((nq + 63) / 64) * ((P + 255) / 256);
-    if (big_blocks >= 2 * static_cast<int64_t>(c->num_cus) && c->knob_mfma_tile != 1) {
+    if (big_blocks >= 16 * static_cast<int64_t>(c->num_cus) && c->knob_mfma_tile != 1) {
         dim3 grid(static_cast<unsigned>((nq + mfma_tile_q(2) - 1) / mfma_tile_q(2)), static_cast<unsigned>((P + mfma_tile_p(2) - 1) / mfma_tile_p(2)));
         hipLaunchKernelGGL((encode_mfma_kernel<TIn, 2, 2>), grid, dim3(256), 0, c->stream, q_dev, nq, d, c->d_alphaT32, c->d_r, c->d_omega, P, c->cfg.m,
                            c->cfg.lambda, c->W, c->TD, hashes_dev, cw, bad_dev, list, cap, cnt, c->alpha_norm_max);
@@ -45,7 +46,7 @@ int launch_encode(fspann_ctx* c, int64_t nq, const TIn* q_dev, uint64_t* codes_d
     unsigned long long guard_cap = 0;
     // auto: the MFMA pre-filter pays from ~5e8 multiply-adds per call (its fixed part: clearing the code words, the exact re-check of the
     // pairs on a bucket edge, four launches).  tools/encode_bench.py, exact vs MFMA: 1 024 x 256 x 128 12 / 31 us, 512 x 256 x 960
-    // 48 / 84, 1 024 x 1 024 x 768 132 / 94, 4 096 x 256 x 960 169 / 113, 8 192 x 1 024 x 768 758 / 288, 262 144 x 256 x 128 1 080 / 502.
+    // 48 / 75, 1 024 x 1 024 x 768 132 / 77, 4 096 x 256 x 960 169 / 94, 8 192 x 1 024 x 768 758 / 273, 262 144 x 256 x 128 1 080 / 502.
     const bool want_mfma = (c->encode_mode == 2) ||
                            (c->encode_mode == 0 && static_cast<double>(nq) * c->P_total * c->cfg.dim >= 5.0e8);
     if (want_mfma && !proj_dev && c->d_alphaT32 && c->W <= 3) {      // (the fused bit-pack epilogue carries three code words: <= 192 bits)
